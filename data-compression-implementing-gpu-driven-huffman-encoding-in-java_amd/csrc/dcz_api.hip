@@ -1,0 +1,522 @@
+// dcz_api.hip -- the C ABI of include/dcz.h: context, workspace, launch sequencing, host-pointer wrappers.
+// No compute happens on the CPU here: every entry point stages bytes and launches the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dcz_internal.h"
+
+using namespace dcz;
+
+struct dcz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // batch workspace
+    uint16_t* seg_hist = nullptr;
+    uint64_t* seg_bitoff = nullptr;
+    uint32_t* code = nullptr;
+    uint8_t* maxlen = nullptr;
+    size_t cap_nseg = 0, cap_K = 0;
+    // staging for the host-pointer API (grow-only)
+    uint8_t* st_in = nullptr;
+    size_t st_in_cap = 0;
+    uint8_t* st_out = nullptr;
+    size_t st_out_cap = 0;
+    uint8_t* st_meta = nullptr;  // 8 KiB of small per-block device fields
+    // profiling
+    bool profiling = false;
+    struct Ev {
+        int kernel;
+        hipEvent_t a, b;
+    };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[DCZ_K_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t launches[DCZ_K_COUNT] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return DCZ_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+hipEvent_t take_event(dcz_ctx* c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct KernelTimer {
+    dcz_ctx* c;
+    hipStream_t s;
+    int kernel;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(dcz_ctx* ctx, hipStream_t st, int k) : c(ctx), s(st), kernel(k) {
+        if (c->profiling) {
+            a = take_event(c);
+            b = take_event(c);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~KernelTimer() {
+        if (c->profiling) {
+            (void)hipEventRecord(b, s);
+            c->pending.push_back({kernel, a, b});
+        }
+    }
+};
+
+int drain_events(dcz_ctx* c) {
+    for (auto& ev : c->pending) {
+        HIPCHK(c, hipEventSynchronize(ev.b));
+        float t = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&t, ev.a, ev.b));
+        c->ms[ev.kernel] += (double)t;
+        c->launches[ev.kernel] += 1;
+        c->pool.push_back(ev.a);
+        c->pool.push_back(ev.b);
+    }
+    c->pending.clear();
+    return DCZ_OK;
+}
+
+struct Geometry {
+    uint32_t K;
+    uint32_t spb;
+    uint64_t nseg;
+};
+
+int geometry(size_t n, size_t block_bytes, Geometry* g) {
+    if (block_bytes == 0) return DCZ_E_INVALID;
+    const size_t K = (n + block_bytes - 1) / block_bytes;
+    if (K > 0x7FFFFFFFull || block_bytes > 0xFFFFFFFFull) return DCZ_E_INVALID;
+    const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;  // a single block never needs more segments than n has
+    g->K = (uint32_t)K;
+    g->spb = (uint32_t)((eff + SEG - 1) / SEG);
+    g->nseg = (uint64_t)g->K * g->spb;
+    return DCZ_OK;
+}
+
+template <typename T>
+int grow(dcz_ctx* c, T** p, size_t* cap, size_t need_elems) {
+    if (need_elems <= *cap && *p) return DCZ_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t elems = need_elems + need_elems / 8 + 64;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(T)));
+    *cap = elems;
+    return DCZ_OK;
+}
+
+int reserve(dcz_ctx* c, const Geometry& g) {
+    if (g.nseg > c->cap_nseg || !c->seg_hist) {
+        if (c->seg_hist) HIPCHK(c, hipFree(c->seg_hist));
+        if (c->seg_bitoff) HIPCHK(c, hipFree(c->seg_bitoff));
+        c->seg_hist = nullptr;
+        c->seg_bitoff = nullptr;
+        c->cap_nseg = 0;
+        const size_t ns = (size_t)g.nseg + 64;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->seg_hist), ns * 256 * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->seg_bitoff), ns * sizeof(uint64_t)));
+        c->cap_nseg = ns;
+    }
+    if (g.K > c->cap_K || !c->code) {
+        if (c->code) HIPCHK(c, hipFree(c->code));
+        if (c->maxlen) HIPCHK(c, hipFree(c->maxlen));
+        c->code = nullptr;
+        c->maxlen = nullptr;
+        c->cap_K = 0;
+        const size_t nk = (size_t)g.K + 64;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->code), nk * 256 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->maxlen), nk));
+        c->cap_K = nk;
+    }
+    return DCZ_OK;
+}
+
+int launch_check(dcz_ctx* c) {
+    HIPCHK(c, hipGetLastError());
+    return DCZ_OK;
+}
+
+// small per-block device fields used by the host-pointer API, carved from st_meta (8 KiB)
+struct Meta {
+    uint32_t* comp_size;  // 1
+    uint64_t* comp_off;   // 1
+    uint64_t* total;      // 1
+    int32_t* status;      // 1
+    int64_t* errpos;      // 1
+    uint32_t* orig_size;  // 1
+    uint8_t* len8;        // 256
+    int32_t* len32;       // 256
+    uint32_t* code;       // 256
+    int64_t* hist;        // 256
+};
+
+Meta meta_of(dcz_ctx* c) {
+    uint8_t* p = c->st_meta;
+    Meta m;
+    m.comp_off = reinterpret_cast<uint64_t*>(p);
+    m.total = reinterpret_cast<uint64_t*>(p + 8);
+    m.errpos = reinterpret_cast<int64_t*>(p + 16);
+    m.comp_size = reinterpret_cast<uint32_t*>(p + 24);
+    m.status = reinterpret_cast<int32_t*>(p + 28);
+    m.orig_size = reinterpret_cast<uint32_t*>(p + 32);
+    m.len8 = p + 256;
+    m.len32 = reinterpret_cast<int32_t*>(p + 512);
+    m.code = reinterpret_cast<uint32_t*>(p + 512 + 1024);
+    m.hist = reinterpret_cast<int64_t*>(p + 512 + 2048);
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+int dcz_ctx_create(int device, dcz_ctx** out) {
+    if (!out) return DCZ_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DCZ_E_NODEVICE;
+    if (device < 0 || device >= n) return DCZ_E_INVALID;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return DCZ_E_NODEVICE;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) return DCZ_E_NODEVICE;  // the code object is gfx950-only
+    dcz_ctx* c = new dcz_ctx();
+    c->device = device;
+    DeviceGuard g(device);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->st_meta), 8192) != hipSuccess) {
+        delete c;
+        return DCZ_E_HIP;
+    }
+    *out = c;
+    return DCZ_OK;
+}
+
+void dcz_ctx_destroy(dcz_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->pending) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    (void)hipFree(c->seg_hist);
+    (void)hipFree(c->seg_bitoff);
+    (void)hipFree(c->code);
+    (void)hipFree(c->maxlen);
+    (void)hipFree(c->st_in);
+    (void)hipFree(c->st_out);
+    (void)hipFree(c->st_meta);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* dcz_strerror(int status) {
+    switch (status) {
+        case DCZ_OK: return "ok";
+        case DCZ_E_INVALID: return "invalid argument";
+        case DCZ_E_NODEVICE: return "no gfx950 device available";
+        case DCZ_E_HIP: return "HIP runtime error";
+        case DCZ_E_CAPACITY: return "output buffer too small";
+        case DCZ_E_BADSTREAM: return "Huffman decode error";
+        case DCZ_E_CODELEN: return "code length exceeds 32";
+        case DCZ_E_BADTABLE: return "code length table is not a prefix code";
+        default: return "unknown status";
+    }
+}
+
+const char* dcz_last_error(const dcz_ctx* c) { return c ? c->err.c_str() : ""; }
+
+int dcz_ctx_reserve(dcz_ctx* c, size_t n, size_t block_bytes) {
+    if (!c) return DCZ_E_INVALID;
+    Geometry g;
+    int r = geometry(n, block_bytes, &g);
+    if (r != DCZ_OK) return r;
+    DeviceGuard dg(c->device);
+    return reserve(c, g);
+}
+
+int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_bytes, void* d_out, size_t out_cap,
+                        uint32_t* d_comp_size, uint64_t* d_comp_off, uint8_t* d_len, int32_t* d_status,
+                        uint64_t* d_total, void* stream) {
+    if (!c || (!d_in && n) || !d_comp_size || !d_comp_off || !d_len || !d_status) return DCZ_E_INVALID;
+    Geometry g;
+    int r = geometry(n, block_bytes, &g);
+    if (r != DCZ_OK) return r;
+    DeviceGuard dg(c->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (g.K == 0) {
+        if (d_total) HIPCHK(c, hipMemsetAsync(d_total, 0, sizeof(uint64_t), s));
+        return DCZ_OK;
+    }
+    if (!d_out) return DCZ_E_INVALID;
+    r = reserve(c, g);
+    if (r != DCZ_OK) return r;
+    const uint8_t* in = static_cast<const uint8_t*>(d_in);
+    {
+        KernelTimer t(c, s, DCZ_K_HISTOGRAM);
+        launch_histogram(in, n, block_bytes, g.spb, g.nseg, c->seg_hist, s);
+    }
+    {
+        KernelTimer t(c, s, DCZ_K_CODEBUILD);
+        launch_codebuild(c->seg_hist, nullptr, n, block_bytes, g.spb, g.K, d_len, c->code, c->maxlen, d_comp_size,
+                         c->seg_bitoff, d_status, s);
+    }
+    {
+        KernelTimer t(c, s, DCZ_K_OFFSETS);
+        launch_offsets(d_comp_size, g.K, d_comp_off, d_total, out_cap, d_status, s);
+    }
+    {
+        KernelTimer t(c, s, DCZ_K_ENCODE);
+        launch_encode(in, n, block_bytes, g.spb, g.K, d_len, c->code, c->maxlen, d_comp_off, c->seg_bitoff, d_status,
+                      static_cast<uint8_t*>(d_out), s);
+    }
+    return launch_check(c);
+}
+
+int dcz_decompress_blocks(dcz_ctx* c, const void* d_comp, size_t comp_bytes, const uint64_t* d_comp_off,
+                          const uint32_t* d_comp_size, const uint32_t* d_orig_size, const uint8_t* d_len, size_t K,
+                          size_t out_stride, void* d_out, int32_t* d_status, int64_t* d_errpos, void* stream) {
+    if (!c || !d_comp_off || !d_comp_size || !d_orig_size || !d_len || !d_status) return DCZ_E_INVALID;
+    if (K > 0x7FFFFFFFull) return DCZ_E_INVALID;
+    if (K == 0) return DCZ_OK;
+    if (!d_out) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    {
+        KernelTimer t(c, s, DCZ_K_DECODE);
+        launch_decode(static_cast<const uint8_t*>(d_comp), comp_bytes, d_comp_off, d_comp_size, d_orig_size, d_len,
+                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, s);
+    }
+    return launch_check(c);
+}
+
+int dcz_histogram(dcz_ctx* c, const uint8_t* data, size_t offset, size_t length, int64_t hist[256]) {
+    if (!c || !hist || (!data && length)) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    Meta m = meta_of(c);
+    Geometry g;
+    int r = geometry(length, length ? length : 1, &g);
+    if (r != DCZ_OK) return r;
+    if (length > 0xFFFFFFFFull) return DCZ_E_INVALID;  // byte[] windows are int-sized in the reference
+    if ((r = grow(c, &c->st_in, &c->st_in_cap, length + 16)) != DCZ_OK) return r;
+    if ((r = reserve(c, g)) != DCZ_OK) return r;
+    if (length) HIPCHK(c, hipMemcpyAsync(c->st_in, data + offset, length, hipMemcpyHostToDevice, s));
+    {
+        KernelTimer t(c, s, DCZ_K_HISTOGRAM);
+        launch_histogram(c->st_in, length, length ? length : 1, g.spb, g.nseg, c->seg_hist, s);
+        launch_sum_hist(c->seg_hist, g.nseg, m.hist, s);
+    }
+    HIPCHK(c, hipMemcpyAsync(hist, m.hist, 256 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return launch_check(c);
+}
+
+int dcz_build_codes(dcz_ctx* c, const int64_t hist[256], int32_t len[256], uint32_t code[256]) {
+    if (!c || !hist || !len || !code) return DCZ_E_INVALID;
+    int64_t h[256];
+    for (int i = 0; i < 256; i++) {
+        if (hist[i] >= (1ll << 37)) return DCZ_E_INVALID;  // packed heap keys hold weights < 2^46
+        h[i] = hist[i] > 0 ? hist[i] : 0;                  // CanonicalHuffman.java:61 only takes freq > 0
+    }
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    Meta m = meta_of(c);
+    HIPCHK(c, hipMemcpyAsync(m.hist, h, sizeof h, hipMemcpyHostToDevice, s));
+    {
+        KernelTimer t(c, s, DCZ_K_CODEBUILD);
+        launch_codebuild(nullptr, m.hist, 0, 1, 0, 1, m.len8, m.code, reinterpret_cast<uint8_t*>(m.orig_size),
+                         m.comp_size, nullptr, m.status, s);
+    }
+    uint8_t l8[256];
+    int32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(l8, m.len8, 256, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(code, m.code, 1024, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&st, m.status, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int i = 0; i < 256; i++) len[i] = l8[i];
+    int r = launch_check(c);
+    return r != DCZ_OK ? r : st;
+}
+
+int dcz_codes_from_lengths(dcz_ctx* c, const int32_t len[256], uint32_t code[256]) {
+    if (!c || !len || !code) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    Meta m = meta_of(c);
+    HIPCHK(c, hipMemcpyAsync(m.len32, len, 1024, hipMemcpyHostToDevice, s));
+    launch_codes_from_lengths(m.len32, m.code, m.status, s);
+    int32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(code, m.code, 1024, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&st, m.status, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int r = launch_check(c);
+    return r != DCZ_OK ? r : st;
+}
+
+int dcz_encode_block(dcz_ctx* c, const uint8_t* data, size_t n, int32_t len_out[256], uint8_t* out, size_t cap,
+                     size_t* out_len) {
+    if (!c || !len_out || !out_len || (!data && n) || (!out && cap)) return DCZ_E_INVALID;
+    *out_len = 0;
+    for (int i = 0; i < 256; i++) len_out[i] = 0;
+    if (n == 0) return DCZ_OK;  // an empty file has no chunk (CpuCompressionService.java:64)
+    if (n > 0x7FFFFFFFull) return DCZ_E_INVALID;  // chunks are Java byte[] (CpuCompressionService.java:38)
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    Meta m = meta_of(c);
+    int r;
+    if ((r = grow(c, &c->st_in, &c->st_in_cap, n + 16)) != DCZ_OK) return r;
+    if ((r = grow(c, &c->st_out, &c->st_out_cap, n + 16)) != DCZ_OK) return r;
+    HIPCHK(c, hipMemcpyAsync(c->st_in, data, n, hipMemcpyHostToDevice, s));
+    r = dcz_compress_blocks(c, c->st_in, n, n, c->st_out, n, m.comp_size, m.comp_off, m.len8, m.status, m.total, s);
+    if (r != DCZ_OK) return r;
+    uint8_t l8[256];
+    uint32_t cs = 0;
+    int32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(l8, m.len8, 256, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&cs, m.comp_size, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&st, m.status, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (st != DCZ_OK) return st;
+    for (int i = 0; i < 256; i++) len_out[i] = l8[i];
+    if (cs > cap) return DCZ_E_CAPACITY;
+    if (cs) HIPCHK(c, hipMemcpy(out, c->st_out, cs, hipMemcpyDeviceToHost));
+    *out_len = cs;
+    return launch_check(c);
+}
+
+int dcz_decode_block(dcz_ctx* c, const uint8_t* comp, size_t comp_size, const int32_t len[256], uint8_t* out,
+                     size_t out_size, int64_t* err_pos) {
+    if (!c || !len || (!comp && comp_size) || (!out && out_size)) return DCZ_E_INVALID;
+    if (err_pos) *err_pos = -1;
+    if (out_size == 0) return DCZ_OK;
+    if (out_size > 0x7FFFFFFFull || comp_size > 0xFFFFFFFFull) return DCZ_E_INVALID;
+    uint8_t l8[256];
+    for (int i = 0; i < 256; i++) {
+        if (len[i] < 0 || len[i] > 32) return DCZ_E_BADTABLE;  // CanonicalHuffman.java:106 would throw
+        l8[i] = (uint8_t)len[i];
+    }
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    Meta m = meta_of(c);
+    int r;
+    if ((r = grow(c, &c->st_in, &c->st_in_cap, comp_size + 32)) != DCZ_OK) return r;
+    if ((r = grow(c, &c->st_out, &c->st_out_cap, out_size + 16)) != DCZ_OK) return r;
+    const uint64_t off0 = 0;
+    const uint32_t cs = (uint32_t)comp_size, os = (uint32_t)out_size;
+    if (comp_size) HIPCHK(c, hipMemcpyAsync(c->st_in, comp, comp_size, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(m.len8, l8, 256, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(m.comp_off, &off0, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(m.comp_size, &cs, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(m.orig_size, &os, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // the small host temporaries above live on this stack frame
+    r = dcz_decompress_blocks(c, c->st_in, comp_size, m.comp_off, m.comp_size, m.orig_size, m.len8, 1, out_size,
+                              c->st_out, m.status, m.errpos, s);
+    if (r != DCZ_OK) return r;
+    int32_t st = 0;
+    int64_t ep = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, m.status, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&ep, m.errpos, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (st != DCZ_OK) {
+        if (err_pos) *err_pos = ep;
+        return st;
+    }
+    HIPCHK(c, hipMemcpy(out, c->st_out, out_size, hipMemcpyDeviceToHost));
+    return launch_check(c);
+}
+
+int dcz_ctx_set_profiling(dcz_ctx* c, int on) {
+    if (!c) return DCZ_E_INVALID;
+    c->profiling = on != 0;
+    return DCZ_OK;
+}
+
+int dcz_ctx_reset_profiling(dcz_ctx* c) {
+    if (!c) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    int r = drain_events(c);
+    for (int i = 0; i < DCZ_K_COUNT; i++) {
+        c->ms[i] = 0;
+        c->launches[i] = 0;
+    }
+    return r;
+}
+
+int dcz_ctx_kernel_time(dcz_ctx* c, int kernel, double* total_ms, uint64_t* launches) {
+    if (!c || kernel < 0 || kernel >= DCZ_K_COUNT) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    int r = drain_events(c);
+    if (total_ms) *total_ms = c->ms[kernel];
+    if (launches) *launches = c->launches[kernel];
+    return r;
+}
+
+int dczu_fill_java_random(dcz_ctx* c, void* d_buf, size_t n, int64_t seed, uint64_t start, void* stream) {
+    if (!c || (!d_buf && n) || (start & 3)) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    launch_fill_java_random(static_cast<uint8_t*>(d_buf), n, seed, start,
+                            stream ? static_cast<hipStream_t>(stream) : c->stream);
+    return launch_check(c);
+}
+
+int dczu_fill_text(dcz_ctx* c, void* d_buf, size_t n, uint64_t seed, uint64_t start, void* stream) {
+    if (!c || (!d_buf && n)) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    launch_fill_text(static_cast<uint8_t*>(d_buf), n, seed, start, stream ? static_cast<hipStream_t>(stream) : c->stream);
+    return launch_check(c);
+}
+
+int dczu_fill_lowentropy(dcz_ctx* c, void* d_buf, size_t n, uint64_t seed, uint64_t start, void* stream) {
+    if (!c || (!d_buf && n)) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    launch_fill_lowentropy(static_cast<uint8_t*>(d_buf), n, seed, start,
+                           stream ? static_cast<hipStream_t>(stream) : c->stream);
+    return launch_check(c);
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// dcz_internal.h -- shared constants, device helpers and kernel launchers of libdczhip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dcz.h"
+
+namespace dcz {
+
+constexpr uint32_t SEG = DCZ_SEGMENT_BYTES;  // bytes of one block handled by one wave in K1 and K3
+constexpr int WAVE = 64;                     // gfx950 wavefront
+
+// ---- host-side launchers (each defined next to its kernel) ---------------------------------
+// K1: per-segment 256-bin histograms.  seg_hist is [nseg][256] u16 (a segment holds <= 32768 bytes).
+void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint64_t nseg,
+                      uint16_t* seg_hist, hipStream_t s);
+// Histogram of a byte window into 256 x i64 (single-block API; sums the segment rows on the device).
+void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s);
+
+// K2: per-block code build + per-segment bit offsets.
+void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t n, size_t block_bytes,
+                      uint32_t segs_per_block, uint32_t K, uint8_t* d_len, uint32_t* d_code, uint8_t* d_maxlen,
+                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s);
+// Canonical codes from stored lengths (CH.generateCanonicalCodesFromLengths), one block per workgroup.
+void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s);
+// Exclusive scan of comp_size -> comp_off, total, capacity check.
+void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total, size_t out_cap,
+                    int32_t* d_status, hipStream_t s);
+
+// K3: encode.
+void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,
+                   const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
+                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s);
+
+// K4: decode.
+void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                   const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
+                   int32_t* d_status, int64_t* d_errpos, hipStream_t s);
+
+// Generators.
+void launch_fill_java_random(uint8_t* d, size_t n, int64_t seed, uint64_t start, hipStream_t s);
+void launch_fill_text(uint8_t* d, size_t n, uint64_t seed, uint64_t start, hipStream_t s);
+void launch_fill_lowentropy(uint8_t* d, size_t n, uint64_t seed, uint64_t start, hipStream_t s);
+
+#if defined(__HIPCC__)
+// ---- device helpers --------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Wave-wide inclusive scan of a u32 with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31): no LDS traffic.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_u32(v), 63);
+}
+
+__device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// Wave-scope ordering of LDS traffic between lanes of ONE wave (LDS executes a wave's operations in
+// issue order; this only stops the compiler from reordering across it).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#endif  // __HIPCC__
+
+}  // namespace dcz

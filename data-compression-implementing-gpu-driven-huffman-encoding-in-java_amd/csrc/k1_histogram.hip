@@ -1,0 +1,153 @@
+// k1_histogram.hip -- K1: 256-bin byte histogram per 32 KiB segment (gfx950).
+//
+// Replaces FrequencyService.computeHistogram (service/FrequencyService.java:16): the CPU version
+// service/cpu/CpuFrequencyService.java:37-46 and the TornadoVM tile kernel service/gpu/TornadoKernels.java:89-100
+// (one work-item per 64 KiB tile; 256 work-items for a 16 MiB chunk).
+//
+// Design (HBM-bound, integer): one WAVE owns one segment and streams it with 16 B/lane coalesced loads.
+// Counting uses LDS atomics into a wave-private histogram that is replicated over the 32 LDS banks:
+//   dword[(bin & 127) * 32 + (lane & 31)], low half = bin < 128, high half = bin >= 128.
+// Lane l only ever touches bank l & 31, so every ds_add_u32 is conflict-free for ANY data
+// distribution (all-zero input included); lanes l and l+32 are serviced in different LDS cycles.
+// A (lane pair, bin) count is at most 1024 per segment, a bin total at most 32768: u16 halves
+// never carry into each other, and the 32 replicas can be summed as packed dwords.
+// No global atomics, no inter-workgroup traffic: K2 sums the segment rows of its block.
+#include "dcz_internal.h"
+
+namespace dcz {
+
+constexpr int K1_WAVES = 4;  // 4 x 16 KiB of LDS per workgroup -> 2 workgroups (8 waves) per CU
+
+__device__ __forceinline__ void hist_add(uint32_t* h, uint32_t col, uint32_t byte) {
+    const uint32_t idx = ((byte & 127u) << 5) + col;
+    const uint32_t val = (byte >> 7) * 0xFFFFu + 1u;  // 1 or 0x10000
+    __hip_atomic_fetch_add(&h[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+__device__ __forceinline__ void hist_add_dword(uint32_t* h, uint32_t col, uint32_t d) {
+    hist_add(h, col, d & 0xFFu);
+    hist_add(h, col, (d >> 8) & 0xFFu);
+    hist_add(h, col, (d >> 16) & 0xFFu);
+    hist_add(h, col, d >> 24);
+}
+
+__device__ __forceinline__ void hist_add_vec(uint32_t* h, uint32_t col, const uint4& v) {
+    hist_add_dword(h, col, v.x);
+    hist_add_dword(h, col, v.y);
+    hist_add_dword(h, col, v.z);
+    hist_add_dword(h, col, v.w);
+}
+
+__global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __restrict__ in, size_t n,
+                                                               size_t block_bytes, uint32_t spb, uint64_t nseg,
+                                                               uint16_t* __restrict__ seg_hist) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[K1_WAVES][128 * 32];
+    const int w = (int)(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const uint64_t seg = (uint64_t)blockIdx.x * K1_WAVES + (uint64_t)w;
+    if (seg >= nseg) return;  // wave-uniform; this kernel has no workgroup barrier
+    uint32_t* h = lds[w];
+    const uint32_t col = (uint32_t)lane & 31u;
+
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(h);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) h4[i * 64 + lane] = z;
+    }
+    wave_lds_fence();
+
+    const uint64_t b = seg / spb, j = seg % spb;
+    const uint64_t bstart = b * (uint64_t)block_bytes;
+    const uint64_t bend = (bstart + block_bytes < n) ? bstart + block_bytes : (uint64_t)n;
+    const uint64_t s0 = bstart + j * (uint64_t)SEG;
+    uint32_t len = 0;
+    if (s0 < bend) len = (uint32_t)((bend - s0 < SEG) ? bend - s0 : SEG);
+    const uint8_t* p = in + s0;
+
+    // unaligned head (only when block_bytes or the base pointer is not a multiple of 16)
+    uint32_t nhead = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
+    if (nhead > len) nhead = len;
+    if ((uint32_t)lane < nhead) hist_add(h, col, p[lane]);
+    const uint4* pv = reinterpret_cast<const uint4*>(p + nhead);
+    const uint32_t nvec = (len - nhead) >> 4;
+
+    // body: 4 x 16 B per lane in flight per step
+    for (uint32_t base = 0; base < nvec; base += 256) {
+        const uint32_t i0 = base + (uint32_t)lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+        uint4 d0, d1, d2, d3;
+        if (base + 256 <= nvec) {
+            d0 = pv[i0];
+            d1 = pv[i1];
+            d2 = pv[i2];
+            d3 = pv[i3];
+            hist_add_vec(h, col, d0);
+            hist_add_vec(h, col, d1);
+            hist_add_vec(h, col, d2);
+            hist_add_vec(h, col, d3);
+        } else {
+            if (i0 < nvec) { d0 = pv[i0]; hist_add_vec(h, col, d0); }
+            if (i1 < nvec) { d1 = pv[i1]; hist_add_vec(h, col, d1); }
+            if (i2 < nvec) { d2 = pv[i2]; hist_add_vec(h, col, d2); }
+            if (i3 < nvec) { d3 = pv[i3]; hist_add_vec(h, col, d3); }
+        }
+    }
+    // tail (< 16 bytes)
+    {
+        const uint32_t done = nhead + (nvec << 4);
+        const uint32_t ntail = len - done;
+        if ((uint32_t)lane < ntail) hist_add(h, col, p[done + lane]);
+    }
+    wave_lds_fence();
+
+    // Sum the 32 replicas. Lane l owns rows l and l+64 (bins l, l+128 and l+64, l+192).  The 16-B
+    // chunk order is rotated by lane>>1 so that every ds_read_b128 lane group touches 16 distinct
+    // 4-bank slots (row parity x chunk) -> conflict-free.
+    uint32_t acc0 = 0, acc1 = 0;
+    const uint4* r0 = reinterpret_cast<const uint4*>(h + (uint32_t)lane * 32u);
+    const uint4* r1 = reinterpret_cast<const uint4*>(h + ((uint32_t)lane + 64u) * 32u);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int q = (t + (lane >> 1)) & 7;
+        const uint4 a = r0[q];
+        const uint4 c = r1[q];
+        acc0 += a.x + a.y + a.z + a.w;
+        acc1 += c.x + c.y + c.z + c.w;
+    }
+    uint16_t* row = seg_hist + seg * 256u;
+    row[lane] = (uint16_t)(acc0 & 0xFFFFu);
+    row[lane + 128] = (uint16_t)(acc0 >> 16);
+    row[lane + 64] = (uint16_t)(acc1 & 0xFFFFu);
+    row[lane + 192] = (uint16_t)(acc1 >> 16);
+}
+
+// Single-window histogram for the host API: sum segment rows into 256 x i64 (d_hist pre-zeroed).
+__global__ __launch_bounds__(256) void k1_sum_rows(const uint16_t* __restrict__ seg_hist, uint64_t nseg,
+                                                   unsigned long long* __restrict__ d_hist) {
+    const uint64_t per = (nseg + gridDim.x - 1) / gridDim.x;
+    const uint64_t a = (uint64_t)blockIdx.x * per;
+    uint64_t e = a + per;
+    if (e > nseg) e = nseg;
+    unsigned long long acc = 0;
+    for (uint64_t s = a; s < e; s++) acc += seg_hist[s * 256u + threadIdx.x];
+    if (acc) atomicAdd(&d_hist[threadIdx.x], acc);
+}
+
+void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint64_t nseg,
+                      uint16_t* seg_hist, hipStream_t s) {
+    if (nseg == 0) return;
+    const uint32_t grid = (uint32_t)((nseg + K1_WAVES - 1) / K1_WAVES);
+    hipLaunchKernelGGL(k1_histogram, dim3(grid), dim3(K1_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block, nseg,
+                       seg_hist);
+}
+
+void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s) {
+    (void)hipMemsetAsync(d_hist, 0, 256 * sizeof(int64_t), s);
+    if (nseg == 0) return;
+    uint32_t grid = (uint32_t)((nseg + 63) / 64);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k1_sum_rows, dim3(grid), dim3(256), 0, s, seg_hist, nseg,
+                       reinterpret_cast<unsigned long long*>(d_hist));
+}
+
+}  // namespace dcz

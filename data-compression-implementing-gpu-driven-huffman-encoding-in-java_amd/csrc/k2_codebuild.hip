@@ -1,0 +1,321 @@
+// k2_codebuild.hip -- K2: per-block canonical Huffman code build on the device (gfx950).
+//
+// Replaces CanonicalHuffman.buildCanonicalCodes (core/CanonicalHuffman.java:19-50):
+//   buildCodeLengths  core/CanonicalHuffman.java:55-80   (java.util.PriorityQueue of HuffmanNode)
+//   extractLengths    core/CanonicalHuffman.java:85-92
+//   generateCanonicalCodes core/CanonicalHuffman.java:99-132
+// and the host-side prefix sum of GpuCompressionService.executePacketEncoding
+// (service/gpu/GpuCompressionService.java:771-779: int[N] bit positions built serially on the CPU) --
+// here only one bit offset per 32 KiB segment is needed, and it comes from the segment histograms:
+//   bits(segment) = sum_s seg_hist[segment][s] * len[s].
+//
+// One workgroup per block.  The PriorityQueue is emulated literally (array binary heap, OpenJDK
+// siftUp/siftDown tie rules) by ONE lane because the code lengths depend on the heap's tie order when
+// equal-weight internal nodes coexist (core/HuffmanNode.java:52-58 compares them equal).  Heap
+// entries are packed u64 = weight<<18 | (symbol+1)<<9 | node id; entries compare by (entry >> 9), so
+// internal nodes (symbol -1 -> 0) sort before leaves of equal weight and two internal nodes of equal
+// weight compare EQUAL, exactly as compareTo does.  The heap is stored shifted by one slot so that
+// the two children of slot k sit in one aligned 16-byte pair (a single ds_read_b128 per level).
+// This kernel is latency-bound (a few hundred heap operations); it runs K blocks concurrently.
+#include "dcz_internal.h"
+
+namespace dcz {
+
+struct CodeLds {
+    __attribute__((aligned(16))) unsigned long long heap[260];  // slot i+1 holds PriorityQueue.queue[i]
+    unsigned long long hist[256];
+    unsigned long long wsum[8];
+    uint32_t cnt[34];
+    uint32_t first[34];
+    uint16_t parent[512];
+    uint8_t len[256];
+    int nsym;
+    int maxlen;
+};
+
+#define HKEY(e) ((e) >> 9)
+
+// PriorityQueue.offer -> siftUp: ties do not move up.
+__device__ __forceinline__ void heap_offer(unsigned long long* q, int& size, unsigned long long x) {
+    int k = size++;
+    const unsigned long long xk = HKEY(x);
+    while (k > 0) {
+        const int parent = (k - 1) >> 1;
+        const unsigned long long e = q[parent + 1];
+        if (xk >= HKEY(e)) break;
+        q[k + 1] = e;
+        k = parent;
+    }
+    q[k + 1] = x;
+}
+
+// PriorityQueue.poll -> siftDown: ties prefer the left child; x stops when x <= child.
+__device__ __forceinline__ unsigned long long heap_poll(unsigned long long* q, int& size) {
+    const unsigned long long result = q[1];
+    const int n = --size;
+    const unsigned long long x = q[n + 1];
+    if (n > 0) {
+        const unsigned long long xk = HKEY(x);
+        int k = 0;
+        const int half = n >> 1;
+        while (k < half) {
+            int child = 2 * k + 1;
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(&q[child + 1]);  // slots 2k+2, 2k+3
+            unsigned long long c = pr.x;
+            if (child + 1 < n && HKEY(c) > HKEY(pr.y)) {
+                c = pr.y;
+                child = child + 1;
+            }
+            if (xk <= HKEY(c)) break;
+            q[k + 1] = c;
+            k = child;
+        }
+        q[k + 1] = x;
+    }
+    return result;
+}
+
+// Code lengths for hist[] in LDS (L.hist) -> L.len, L.maxlen, L.nsym.  All 256 threads call this.
+__device__ void build_lengths(CodeLds& L) {
+    const int tid = (int)threadIdx.x;
+    const unsigned long long f = L.hist[tid];
+    const int nsym = __syncthreads_count(f > 0);
+    if (tid == 0) {
+        L.nsym = nsym;
+        L.maxlen = 0;
+    }
+    L.len[tid] = 0;
+    __syncthreads();
+    if (nsym == 0) return;  // core/CanonicalHuffman.java:30-32
+    if (nsym == 1) {        // core/CanonicalHuffman.java:35-45: the single symbol gets length 1, code 0
+        if (f > 0) {
+            L.len[tid] = 1;
+            L.maxlen = 1;
+        }
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) {
+        int size = 0;
+        for (int s = 0; s < 256; s++) {  // core/CanonicalHuffman.java:59-63: leaves in symbol order
+            const unsigned long long w = L.hist[s];
+            if (w > 0) heap_offer(L.heap, size, (w << 18) | ((unsigned long long)(s + 1) << 9) | (unsigned long long)s);
+        }
+        int nn = 256;
+        while (size > 1) {  // core/CanonicalHuffman.java:66-70
+            const unsigned long long l = heap_poll(L.heap, size);
+            const unsigned long long r = heap_poll(L.heap, size);
+            L.parent[l & 511u] = (uint16_t)nn;
+            L.parent[r & 511u] = (uint16_t)nn;
+            const unsigned long long w = (l >> 18) + (r >> 18);
+            heap_offer(L.heap, size, (w << 18) | (unsigned long long)nn);
+            nn++;
+        }
+        L.parent[L.heap[1] & 511u] = 0xFFFFu;
+    }
+    __syncthreads();
+    // core/CanonicalHuffman.java:85-92 extractLengths: depth of each leaf
+    int d = 0;
+    if (f > 0) {
+        int x = tid;
+        while (true) {
+            const int p = L.parent[x];
+            if (p == 0xFFFF) break;
+            x = p;
+            d++;
+        }
+        L.len[tid] = (uint8_t)(d > 255 ? 255 : d);
+        atomicMax(&L.maxlen, d);
+    }
+    __syncthreads();
+}
+
+// core/CanonicalHuffman.java:99-132 generateCanonicalCodes, from L.len (all <= 32). Returns this thread's code.
+__device__ uint32_t canonical_code(CodeLds& L) {
+    const int tid = (int)threadIdx.x;
+    if (tid < 34) L.cnt[tid] = 0;
+    __syncthreads();
+    const int l = L.len[tid];
+    if (l > 0) atomicAdd(&L.cnt[l], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        L.first[0] = 0;
+        for (int i = 1; i <= 32; i++) {  // core/CanonicalHuffman.java:112-117
+            c = (c + L.cnt[i - 1]) << 1;
+            L.first[i] = c;
+        }
+    }
+    __syncthreads();
+    uint32_t code = 0;
+    if (l > 0) {  // core/CanonicalHuffman.java:123-129: ascending symbol order within a length
+        uint32_t rank = 0;
+        for (int s = 0; s < tid; s++) rank += (L.len[s] == l) ? 1u : 0u;
+        code = L.first[l] + rank;
+    }
+    return code;
+}
+
+__device__ __forceinline__ unsigned long long block_reduce_add_u64(unsigned long long v, CodeLds& L) {
+    v = wave_reduce_add_u64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) L.wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+}
+
+__global__ __launch_bounds__(256) void k2_codebuild(const uint16_t* __restrict__ seg_hist,
+                                                    const long long* __restrict__ hist_in, size_t n,
+                                                    size_t block_bytes, uint32_t spb, uint32_t K,
+                                                    uint8_t* __restrict__ d_len, uint32_t* __restrict__ d_code,
+                                                    uint8_t* __restrict__ d_maxlen, uint32_t* __restrict__ d_comp_size,
+                                                    unsigned long long* __restrict__ d_seg_bitoff,
+                                                    int32_t* __restrict__ d_status) {
+    __shared__ CodeLds L;
+    const uint32_t b = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+
+    // number of segments this block really has (the last block may be short)
+    uint32_t nsb = 0;
+    if (seg_hist) {
+        const uint64_t bstart = (uint64_t)b * block_bytes;
+        const uint64_t bend = (bstart + block_bytes < n) ? bstart + block_bytes : (uint64_t)n;
+        nsb = (uint32_t)((bend - bstart + SEG - 1) / SEG);
+    }
+    const uint16_t* rows = seg_hist ? seg_hist + (uint64_t)b * spb * 256u : nullptr;
+
+    unsigned long long f = 0;
+    if (seg_hist) {
+        for (uint32_t j = 0; j < nsb; j++) f += rows[(uint64_t)j * 256u + tid];
+    } else {
+        f = (unsigned long long)hist_in[(uint64_t)b * 256u + tid];
+    }
+    L.hist[tid] = f;
+    __syncthreads();
+
+    build_lengths(L);
+    const int maxlen = L.maxlen;
+    const bool too_long = maxlen > 32;  // core/CanonicalHuffman.java:102-106 would throw
+    if (too_long) L.len[tid] = 0;
+    __syncthreads();
+    const uint32_t code = canonical_code(L);
+    const uint32_t l = L.len[tid];
+    d_len[(uint64_t)b * 256u + tid] = (uint8_t)l;
+    d_code[(uint64_t)b * 256u + tid] = code;
+
+    const unsigned long long bits = block_reduce_add_u64(f * (unsigned long long)l, L);
+    if (tid == 0) {
+        d_maxlen[b] = (uint8_t)(too_long ? 0 : maxlen);
+        d_comp_size[b] = too_long ? 0u : (uint32_t)((bits + 7) >> 3);
+        d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
+    }
+
+    // per-segment bit offsets inside the block: exclusive scan of bits(segment)
+    if (seg_hist && d_seg_bitoff) {
+        unsigned long long carry = 0;
+        for (uint32_t c0 = 0; c0 < spb; c0 += 256) {
+            const uint32_t j = c0 + (uint32_t)tid;
+            unsigned long long sb = 0;
+            if (j < nsb) {
+                const uint16_t* r = rows + (uint64_t)j * 256u;
+                uint32_t acc = 0;
+                for (int s = 0; s < 256; s += 2) {
+                    const uint32_t pr = *reinterpret_cast<const uint32_t*>(r + s);
+                    acc += (pr & 0xFFFFu) * L.len[s] + (pr >> 16) * L.len[s + 1];
+                }
+                sb = acc;
+            }
+            // block-wide exclusive scan of sb
+            unsigned long long inc = sb;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long t = __shfl_up(inc, o, 64);
+                if ((tid & 63) >= o) inc += t;
+            }
+            __syncthreads();
+            if ((tid & 63) == 63) L.wsum[tid >> 6] = inc;
+            __syncthreads();
+            unsigned long long wbase = 0;
+            for (int w = 0; w < (tid >> 6); w++) wbase += L.wsum[w];
+            const unsigned long long tot = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+            if (j < spb) d_seg_bitoff[(uint64_t)b * spb + j] = carry + wbase + inc - sb;
+            carry += tot;
+        }
+    }
+    (void)K;
+}
+
+// CanonicalHuffman.generateCanonicalCodesFromLengths (core/CanonicalHuffman.java:141-146) for one table.
+__global__ __launch_bounds__(256) void k2_codes_from_lengths(const int32_t* __restrict__ len32,
+                                                             uint32_t* __restrict__ d_code,
+                                                             int32_t* __restrict__ d_status) {
+    __shared__ CodeLds L;
+    const int tid = (int)threadIdx.x;
+    const int32_t l = len32[tid];
+    const int bad = __syncthreads_or(l < 0 || l > 32);  // core/CanonicalHuffman.java:106 would throw
+    L.len[tid] = bad ? 0 : (uint8_t)l;
+    __syncthreads();
+    const uint32_t code = canonical_code(L);
+    d_code[tid] = bad ? 0u : code;
+    if (tid == 0) d_status[0] = bad ? DCZ_E_BADTABLE : DCZ_OK;
+}
+
+// Payload offsets: exclusive scan of comp_size over the K blocks of this call, total, capacity check.
+__global__ __launch_bounds__(1024) void k2_offsets(const uint32_t* __restrict__ comp_size, uint32_t K,
+                                                   unsigned long long* __restrict__ comp_off,
+                                                   unsigned long long* __restrict__ d_total,
+                                                   unsigned long long out_cap, int32_t* __restrict__ d_status) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < K; c0 += 1024) {
+        const uint32_t k = c0 + (uint32_t)tid;
+        const unsigned long long v = (k < K) ? comp_size[k] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(inc, o, 64);
+            if ((tid & 63) >= o) inc += t;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        unsigned long long wbase = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < (tid >> 6)) wbase += wsum[w];
+            tot += wsum[w];
+        }
+        const unsigned long long off = carry_s + wbase + inc - v;
+        if (k < K) {
+            comp_off[k] = off;
+            if (off + v > out_cap && d_status[k] == DCZ_OK) d_status[k] = DCZ_E_CAPACITY;
+        }
+        __syncthreads();
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && d_total) *d_total = carry_s;
+}
+
+void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t n, size_t block_bytes,
+                      uint32_t segs_per_block, uint32_t K, uint8_t* d_len, uint32_t* d_code, uint8_t* d_maxlen,
+                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s) {
+    if (K == 0) return;
+    hipLaunchKernelGGL(k2_codebuild, dim3(K), dim3(256), 0, s, seg_hist, reinterpret_cast<const long long*>(d_hist_in),
+                       n, block_bytes, segs_per_block, K, d_len, d_code, d_maxlen, d_comp_size,
+                       reinterpret_cast<unsigned long long*>(d_seg_bitoff), d_status);
+}
+
+void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s) {
+    hipLaunchKernelGGL(k2_codes_from_lengths, dim3(1), dim3(256), 0, s, d_len32, d_code, d_status);
+}
+
+void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total, size_t out_cap,
+                    int32_t* d_status, hipStream_t s) {
+    hipLaunchKernelGGL(k2_offsets, dim3(1), dim3(1024), 0, s, d_comp_size, K,
+                       reinterpret_cast<unsigned long long*>(d_comp_off),
+                       reinterpret_cast<unsigned long long*>(d_total), (unsigned long long)out_cap, d_status);
+}
+
+}  // namespace dcz

@@ -1,0 +1,306 @@
+// k3_encode.hip -- K3: codeword lookup + variable-length MSB-first bit packing (gfx950).
+//
+// Replaces CpuCompressionService.encodeChunk + BitOutputStream (service/cpu/CpuCompressionService.java:303-315,
+// :711-737: one bit per loop iteration) and the TornadoVM path GpuCompressionService.executePacketEncoding +
+// TornadoKernels.encodePacketKernel (service/gpu/GpuCompressionService.java:758-831, service/gpu/TornadoKernels.java:115-205:
+// one work-item per OUTPUT word, binary search over an int[N] bit-position array built on the host).
+//
+// Output format (frozen): symbols in input order, codeword MSB first, stream bit i
+// lives in byte i>>3 at bit 7-(i&7), last byte zero padded; blocks are byte aligned and concatenated.
+//
+// Design.  One WAVE owns one 32 KiB segment of a block; its first bit offset comes from K2
+// (d_seg_bitoff), so waves never wait for each other and there is no inter-workgroup traffic.
+//   * input: 16 B/lane coalesced loads (1 KiB per wave instruction), next chunk prefetched;
+//   * codebook: LDS, 256 entries of code<<6|len replicated over the 32 banks (entry s of replica r at
+//     dword s*32+r, lane l reads replica l&31) -> conflict-free ds_read_b32 for any data;
+//   * each lane concatenates G consecutive codewords in registers (G=4 when maxlen<=16, G=2 when
+//     maxlen<=26; a wide path with 64-bit entries covers maxlen<=32), a DPP wave scan of the lane
+//     bit counts gives every lane its bit offset (no LDS, no ballot needed);
+//   * lanes OR their strings into a per-wave 4 KiB LDS ring (ds_or_b32), indexed by stream position
+//     relative to a 16-byte-aligned origin of the OUTPUT address, so that complete 16-byte chunks
+//     are byte-swapped and stored with one coalesced global_store_dwordx4 per lane;
+//   * a byte belongs to the segment that holds its first bit: the owner completes its last byte
+//     by encoding up to 7 look-ahead symbols of the next segment, and never writes the byte its
+//     first bits fall into.  Every output byte has exactly one writer: no global atomics.
+#include "dcz_internal.h"
+
+namespace dcz {
+
+constexpr int K3_WAVES = 8;          // waves (= segments) per workgroup
+constexpr int RING_WORDS = 1024;     // 4 KiB per wave = 32768 bits
+constexpr uint32_t RING_MASK = RING_WORDS - 1;
+
+struct EncState {
+    uint32_t* ring;   // per-wave LDS ring (big-endian bit order inside each dword)
+    uint8_t* gbase;   // global address of relative byte 0 (16-byte aligned)
+    uint32_t rpos;    // next free bit, relative to the origin
+    uint32_t rflush;  // next byte to store, relative to the origin
+};
+
+// OR the low `l` bits of g (1 <= l <= 64) into the ring at relative bit position p.
+__device__ __forceinline__ void ring_or(uint32_t* ring, uint32_t p, unsigned long long g, uint32_t l) {
+    if (l == 0) return;
+    const unsigned long long ga = g << (64u - l);
+    const uint32_t sh = p & 31u;
+    const uint32_t w0 = p >> 5;
+    const unsigned long long t = ga >> sh;
+    const uint32_t x0 = (uint32_t)(t >> 32), x1 = (uint32_t)t;
+    __hip_atomic_fetch_or(&ring[w0 & RING_MASK], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (sh + l > 32u)
+        __hip_atomic_fetch_or(&ring[(w0 + 1) & RING_MASK], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (sh + l > 64u) {
+        const uint32_t x2 = (uint32_t)((((unsigned long long)(uint32_t)ga) << 32) >> sh);
+        __hip_atomic_fetch_or(&ring[(w0 + 2) & RING_MASK], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+__device__ __forceinline__ uint32_t ring_byte(const uint32_t* ring, uint32_t rb) {
+    const uint32_t w = ring[(rb >> 2) & RING_MASK];
+    return (w >> (24u - 8u * (rb & 3u))) & 0xFFu;
+}
+
+// Store every relative byte in [st.rflush, upto) and zero the ring chunks that are completely done.
+// `upto` is wave-uniform.  Whole 16-byte chunks go out as one dwordx4 per lane.
+__device__ __forceinline__ void ring_flush(EncState& st, uint32_t upto, int lane) {
+    wave_lds_fence();
+    while (st.rflush < upto) {
+        const uint32_t f = st.rflush;
+        if ((f & 15u) != 0u || upto - f < 16u) {
+            // ragged head or tail: byte stores (at most 15 bytes)
+            uint32_t e = (f | 15u) + 1u;
+            if (e > upto) e = upto;
+            if ((uint32_t)lane < e - f) st.gbase[f + lane] = (uint8_t)ring_byte(st.ring, f + (uint32_t)lane);
+            wave_lds_fence();
+            if ((e & 15u) == 0u && (uint32_t)lane < 4u) st.ring[((f >> 4) * 4u + (uint32_t)lane) & RING_MASK] = 0u;
+            st.rflush = e;
+        } else {
+            uint32_t nc = (upto - f) >> 4;
+            if (nc > 64u) nc = 64u;
+            if ((uint32_t)lane < nc) {
+                const uint32_t c = (f >> 4) + (uint32_t)lane;
+                uint4* rp = reinterpret_cast<uint4*>(&st.ring[(c * 4u) & RING_MASK]);
+                uint4 v = *rp;
+                v.x = bswap32(v.x);
+                v.y = bswap32(v.y);
+                v.z = bswap32(v.z);
+                v.w = bswap32(v.w);
+                *reinterpret_cast<uint4*>(st.gbase + (size_t)c * 16u) = v;
+                *rp = make_uint4(0, 0, 0, 0);
+            }
+            st.rflush = f + nc * 16u;
+        }
+        wave_lds_fence();
+    }
+}
+
+// Read the 16 bytes of this lane for the chunk at `p` (valid bytes: nb, 0..16). `fast` = 16-byte aligned source.
+__device__ __forceinline__ uint4 load_lane16(const uint8_t* p, int nb, bool fast) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (nb >= 16 && fast) {
+        v = *reinterpret_cast<const uint4*>(p);
+    } else if (nb > 0) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++)
+            if (i < nb) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+// Packed 32-bit entries (code << 6 | len), G symbols per register string.
+template <int G>
+__device__ __forceinline__ void encode_chunk_packed(EncState& st, const uint32_t* lut, uint32_t col, const uint4& d,
+                                                    int nb, int lane) {
+    const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+    unsigned long long gs[16 / G];
+    uint32_t gl[16 / G];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < 16 / G; q++) {
+        unsigned long long g = 0;
+        uint32_t l = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const int i = q * G + k;
+            const uint32_t sym = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            uint32_t e = lut[(sym << 5) + col];
+            if (i >= nb) e = 0;
+            const uint32_t li = e & 63u;
+            g = (g << li) | (unsigned long long)(e >> 6);
+            l += li;
+        }
+        gs[q] = g;
+        gl[q] = l;
+        total += l;
+    }
+    const uint32_t inc = wave_inclusive_scan_u32(total);
+    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint32_t p = st.rpos + inc - total;
+#pragma unroll
+    for (int q = 0; q < 16 / G; q++) {
+        ring_or(st.ring, p, gs[q], gl[q]);
+        p += gl[q];
+    }
+    st.rpos += wave_total;
+    (void)lane;
+}
+
+// Wide entries (code<<8 | len as u64, unreplicated): any length up to 32. 8 symbols per lane per step.
+__device__ __forceinline__ void encode_chunk_wide(EncState& st, const unsigned long long* lut64, uint32_t lo,
+                                                  uint32_t hi, int nb) {
+    const uint32_t dw[2] = {lo, hi};
+    unsigned long long cs[8];
+    uint32_t ls[8];
+    uint32_t total = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t sym = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        unsigned long long e = lut64[sym];
+        if (i >= nb) e = 0;
+        ls[i] = (uint32_t)(e & 0xFFu);
+        cs[i] = e >> 8;
+        total += ls[i];
+    }
+    const uint32_t inc = wave_inclusive_scan_u32(total);
+    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint32_t p = st.rpos + inc - total;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        ring_or(st.ring, p, cs[i], ls[i]);
+        p += ls[i];
+    }
+    st.rpos += wave_total;
+}
+
+__global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __restrict__ in, size_t n, size_t block_bytes,
+                                                            uint32_t spb, uint32_t groups_per_block,
+                                                            const uint8_t* __restrict__ d_len,
+                                                            const uint32_t* __restrict__ d_code,
+                                                            const uint8_t* __restrict__ d_maxlen,
+                                                            const unsigned long long* __restrict__ d_comp_off,
+                                                            const unsigned long long* __restrict__ d_seg_bitoff,
+                                                            const int32_t* __restrict__ d_status,
+                                                            uint8_t* __restrict__ out) {
+    // one array: [0, 8192) codebook (32 KiB), then 8 rings of 1024 dwords (32 KiB)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 32 + K3_WAVES * RING_WORDS];
+    const uint32_t b = blockIdx.x / groups_per_block;
+    const uint32_t grp = blockIdx.x % groups_per_block;
+    const int tid = (int)threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+
+    if (d_status[b] != DCZ_OK) return;  // workgroup-uniform
+    const uint32_t maxlen = d_maxlen[b];
+    const bool wide = maxlen > 26;
+
+    // codebook -> LDS
+    uint32_t* lut = lds;
+    unsigned long long* lut64 = reinterpret_cast<unsigned long long*>(lds);
+    if (!wide) {
+        for (int i = tid; i < 256 * 32; i += K3_WAVES * 64) {
+            const int s = i >> 5;
+            lut[i] = (d_code[(uint64_t)b * 256u + s] << 6) | (uint32_t)d_len[(uint64_t)b * 256u + s];
+        }
+    } else {
+        for (int s = tid; s < 256; s += K3_WAVES * 64)
+            lut64[s] = ((unsigned long long)d_code[(uint64_t)b * 256u + s] << 8) |
+                       (unsigned long long)d_len[(uint64_t)b * 256u + s];
+    }
+    uint32_t* ring = lds + 256 * 32 + w * RING_WORDS;
+    {
+        uint4* r4 = reinterpret_cast<uint4*>(ring);
+#pragma unroll
+        for (int i = 0; i < RING_WORDS / 4 / 64; i++) r4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    const uint64_t bstart = (uint64_t)b * block_bytes;
+    const uint64_t bend = (bstart + block_bytes < n) ? bstart + block_bytes : (uint64_t)n;
+    const uint32_t blen = (uint32_t)(bend - bstart);
+    const uint32_t nsb = (blen + SEG - 1) / SEG;
+    const uint32_t j = grp * K3_WAVES + (uint32_t)w;
+    if (j >= nsb) return;  // wave-uniform; no workgroup barrier below
+
+    const uint32_t soff = j * SEG;
+    const uint32_t slen = (blen - soff < SEG) ? blen - soff : SEG;
+    const uint8_t* src = in + bstart + soff;
+    const bool last_seg = (j + 1 == nsb);
+
+    // output coordinates: virtual bit v = 8*(address & 15) + bit offset in block; origin = 16-byte chunk holding v0
+    uint8_t* const blk_out = out + d_comp_off[b];
+    const uint32_t a = (uint32_t)((uintptr_t)blk_out & 15u);
+    const unsigned long long v0 = 8ull * a + d_seg_bitoff[(uint64_t)b * spb + j];
+    const unsigned long long origin = v0 & ~127ull;
+    EncState st;
+    st.ring = ring;
+    st.gbase = (blk_out - a) + (origin >> 3);
+    st.rpos = (uint32_t)(v0 - origin);
+    st.rflush = (st.rpos + 7u) >> 3;  // first byte whose first bit is ours
+    const uint32_t col = (uint32_t)lane & 31u;
+    const bool fast = (((uintptr_t)src) & 15u) == 0u;
+
+    if (!wide) {
+        const uint32_t nchunks = (slen + 1023u) >> 10;
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        {
+            const int nb = (int)slen - lane * 16;
+            cur = load_lane16(src + lane * 16, nb, fast);
+        }
+        for (uint32_t c = 0; c < nchunks; c++) {
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (c + 1 < nchunks) {
+                const uint32_t o = (c + 1) * 1024u + (uint32_t)lane * 16u;
+                nxt = load_lane16(src + o, (int)slen - (int)o, fast);
+            }
+            const int nb = (int)slen - (int)(c * 1024u) - lane * 16;
+            if (maxlen <= 16)
+                encode_chunk_packed<4>(st, lut, col, cur, nb, lane);
+            else
+                encode_chunk_packed<2>(st, lut, col, cur, nb, lane);
+            ring_flush(st, (st.rpos >> 7) << 4, lane);
+            cur = nxt;
+        }
+    } else {
+        const uint32_t nchunks = (slen + 511u) >> 9;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t o = c * 512u + (uint32_t)lane * 8u;
+            const int nb = (int)slen - (int)o;
+            uint32_t lo = 0, hi = 0;
+            for (int i = 0; i < 8; i++)
+                if (i < nb) {
+                    const uint32_t by = src[o + i];
+                    if (i < 4) lo |= by << (8 * i); else hi |= by << (8 * (i - 4));
+                }
+            encode_chunk_wide(st, lut64, lo, hi, nb);
+            ring_flush(st, (st.rpos >> 7) << 4, lane);
+        }
+    }
+
+    // Last byte of the segment: complete it with look-ahead symbols of the next segment (at most 7 bits
+    // are needed and every codeword has at least 1 bit), or leave the zero padding at the end of the block.
+    const uint32_t own_end = (st.rpos + 7u) >> 3;
+    if (!last_seg && (st.rpos & 7u) != 0u) {
+        unsigned long long cd = 0;
+        uint32_t l = 0;
+        if (lane < 7 && soff + slen + (uint32_t)lane < blen) {
+            const uint32_t sym = src[slen + lane];
+            cd = d_code[(uint64_t)b * 256u + sym];
+            l = d_len[(uint64_t)b * 256u + sym];
+        }
+        const uint32_t inc = wave_inclusive_scan_u32(l);
+        ring_or(st.ring, st.rpos + inc - l, cd, l);
+    }
+    ring_flush(st, own_end, lane);
+}
+
+void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,
+                   const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
+                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s) {
+    if (K == 0) return;
+    const uint32_t gpb = (segs_per_block + K3_WAVES - 1) / K3_WAVES;
+    hipLaunchKernelGGL(k3_encode, dim3(K * gpb), dim3(K3_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block, gpb,
+                       d_len, d_code, d_maxlen, reinterpret_cast<const unsigned long long*>(d_comp_off),
+                       reinterpret_cast<const unsigned long long*>(d_seg_bitoff), d_status, d_out);
+}
+
+}  // namespace dcz

@@ -1,0 +1,431 @@
+"""GPU parity tests: the HIP path (through the C ABI, libdczhip.so) against the CPU oracle, bit for bit.
+
+Integer/byte work: the bar is exact equality of histograms, code lengths, codewords, payload bytes,
+sizes, offsets and decoded bytes.  Full-size cases use size-independent properties (round trip on
+device, payload == input for 8-bit codes, sizes from histograms)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import pin_input
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def hip_compress(svc, data, block_bytes):
+    torch = _torch()
+    t = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    blk = svc.compress_device(t, block_bytes)
+    torch.cuda.synchronize()
+    total = int(blk.total.item())
+    return (blk, blk.payload[:total].cpu().numpy(), blk.comp_size.cpu().numpy().astype(np.uint32),
+            blk.comp_off.cpu().numpy().astype(np.uint64), blk.code_lengths.cpu().numpy().astype(np.int32),
+            blk.status.cpu().numpy())
+
+
+def hip_decompress(svc, blk, n, block_bytes):
+    torch = _torch()
+    K = blk.num_chunks
+    orig = torch.tensor([min(block_bytes, n - k * block_bytes) for k in range(K)], dtype=torch.int32, device="cuda")
+    stride = (block_bytes + 15) & ~15
+    out, status, errpos = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths,
+                                                stride)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()[:K]
+    o = out.cpu().numpy()
+    dec = np.concatenate([o[k * stride:k * stride + int(orig[k])] for k in range(K)]) if K else np.zeros(0, np.uint8)
+    return dec, st, errpos.cpu().numpy()[:K]
+
+
+def assert_parity(svc, orc, data, block_bytes):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    blk, pay, sizes, offs, lens, status = hip_compress(svc, data, block_bytes)
+    opay, osizes, ooffs, olens = orc.compress_blocks(data, block_bytes)
+    assert (status == 0).all()
+    assert (lens == olens).all(), "code lengths differ from the oracle"
+    assert (sizes == osizes).all(), "compressed sizes differ"
+    assert (offs == ooffs).all(), "payload offsets differ"
+    assert pay.size == opay.size
+    if not (pay == opay).all():
+        i = int(np.nonzero(pay != opay)[0][0])
+        raise AssertionError("payload differs at byte %d of %d (hip %02x oracle %02x)" % (i, pay.size, pay[i], opay[i]))
+    dec, st, _ = hip_decompress(svc, blk, data.size, block_bytes)
+    assert (st == 0).all()
+    assert dec.size == data.size and (dec == data).all(), "decode differs from the input"
+    return blk
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_library_is_native_and_loaded(pkg, svc):
+    assert pkg.lib().dcz_device_count() >= 1
+    assert svc.is_available()
+    with open("/proc/self/maps") as f:
+        assert "libdczhip.so" in f.read()  # the in-tree HIP library is what this process runs
+
+
+def test_histogram_kats_through_abi(pkg, vectors):
+    fs = pkg.HipFrequencyService(device=0)
+    for kat in vectors["histogram_kats"]:
+        if "data" in kat:
+            data = np.array(kat["data"], dtype=np.uint8)
+        elif kat["recipe"] == "identity256":
+            data = np.arange(256, dtype=np.uint8)
+        else:
+            data = np.array([5] * 50 + [10] * 50, dtype=np.uint8)
+        h = fs.compute_histogram(data, kat["offset"], kat["length"])
+        assert h.sum() == kat["length"]
+        if "expect_all" in kat:
+            assert (h == kat["expect_all"]).all()
+        for k, v in kat.get("expect", {}).items():
+            assert h[int(k)] == v, kat["src"]
+    # CpuFrequencyServiceTest.java:52-67: 128 KiB of i % 10
+    d = (np.arange(128 * 1024) % 10).astype(np.uint8)
+    assert (fs.compute_histogram(d) == np.bincount(d, minlength=256)).all()
+    assert fs.compute_histogram(np.zeros(0, np.uint8)).sum() == 0
+    fs.close()
+
+
+@pytest.mark.parametrize("n,off,ln", [(1, 0, 1), (15, 3, 9), (1000, 1, 998), (32768, 0, 32768), (32769, 0, 32769),
+                                      (100000, 7, 99990), (3 * 32768 + 17, 5, 3 * 32768)])
+def test_histogram_windows(pkg, orc, n, off, ln):
+    fs = pkg.HipFrequencyService(device=0)
+    for gen in (lambda: orc.java_random_bytes(n, n), lambda: orc.gen_lowentropy(n, 0, n),
+                lambda: np.zeros(n, np.uint8), lambda: np.full(n, 255, np.uint8)):
+        d = gen()
+        assert (fs.compute_histogram(d, off, ln) == orc.histogram(d, off, ln)).all()
+    fs.close()
+
+
+def _tie_histograms():
+    hs = []
+    for m in (2, 3, 5, 6, 7, 9, 26, 100, 255, 256):  # all-equal counts, non-powers of two included
+        h = np.zeros(256, np.int64)
+        h[:m] = 7
+        hs.append(h)
+    h = np.zeros(256, np.int64)
+    h[:40] = [1 << (i // 2) for i in range(40)]  # 1,1,2,2,4,4,...
+    hs.append(h)
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    h = np.zeros(256, np.int64)
+    h[100:130] = fib  # depth 29
+    hs.append(h)
+    h = np.zeros(256, np.int64)
+    h[[3, 200]] = [5, 1 << 36]
+    hs.append(h)
+    h = np.zeros(256, np.int64)
+    h[0x41] = 2048  # single symbol
+    hs.append(h)
+    hs.append(np.zeros(256, np.int64))  # no symbol
+    # speed_test_input.bin counts (Phase3IntegrationTest.java:99-142): 16 x 20200, 20188, 9 x 20100
+    h = np.zeros(256, np.int64)
+    h[0x41:0x41 + 16] = 20200
+    h[0x41 + 16] = 20188
+    h[0x41 + 17:0x41 + 26] = 20100
+    hs.append(h)
+    rng = np.random.default_rng(11)
+    for _ in range(60):  # jqwik generator of HuffmanPropertyTest.java:80-92
+        hs.append(rng.integers(0, 1001, 256).astype(np.int64))
+    for _ in range(20):  # tie-heavy: tiny alphabets of counts
+        hs.append(rng.integers(0, 4, 256).astype(np.int64))
+    for _ in range(20):
+        hs.append((rng.integers(1, 3, 256) * 4096).astype(np.int64))
+    return hs
+
+
+def test_code_build_matches_priority_queue_oracle(svc, orc):
+    for h in _tie_histograms():
+        lens, codes = svc.build_codes(h)
+        olens, ocodes = orc.build_canonical_codes(h)
+        assert (lens == olens).all(), "code lengths differ for hist %s" % h[h > 0][:12]
+        assert (codes == ocodes).all()
+        assert (svc.codes_from_lengths(olens) == ocodes).all()
+
+
+def test_code_length_over_32_is_an_error(pkg, svc):
+    fib = [1, 1]
+    while len(fib) < 36:
+        fib.append(fib[-1] + fib[-2])
+    h = np.zeros(256, np.int64)
+    h[:36] = fib  # depth 35 -> ArrayIndexOutOfBounds in CanonicalHuffman.java:106
+    with pytest.raises(pkg.DczError) as e:
+        svc.build_codes(h)
+    assert e.value.status == pkg.native.DCZ_E_CODELEN
+    bad = np.zeros(256, np.int32)
+    bad[0] = 33
+    with pytest.raises(pkg.DczError) as e:
+        svc.codes_from_lengths(bad)
+    assert e.value.status == pkg.native.DCZ_E_BADTABLE
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_reference_payload_pins(svc, orc, vectors, idx):
+    pin = vectors["payload_pins"][idx]
+    data = pin_input(orc, pin)
+    chunk = 1 << 20 if pin["name"] == "mod256_3mib" else max(data.size, 1)
+    blk, pay, sizes, offs, lens, status = hip_compress(svc, data, chunk)
+    assert pay.size == pin["payload_size"], pin["src"]
+    if "payload_hex" in pin:
+        assert pay.tobytes().hex() == pin["payload_hex"]
+    if pin.get("payload_all_zero"):
+        assert not pay.any()
+    if pin.get("payload_equals_input"):
+        assert (pay == data).all() and (lens == 8).all()
+    assert_parity(svc, orc, data, chunk)
+    # and through the single-chunk host-pointer ABI (processChunk / decodeChunkParallel seam)
+    p2, l2 = svc.encode_chunk(data[:chunk])
+    op, ol = orc.encode_block(data[:chunk])
+    assert (l2 == ol).all() and p2.size == op.size and (p2 == op).all()
+    assert (svc.decode_chunk(p2, l2, min(chunk, data.size)) == data[:chunk]).all()
+
+
+SIZES = [1, 2, 7, 16, 17, 63, 64, 65, 1000, 1023, 1024, 1025, 4095, 16384, 32767, 32768, 32769, 65536 + 3,
+         200000, 3 * 32768 + 31, 1 << 20]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_parity_sizes_text(svc, orc, n):
+    assert_parity(svc, orc, orc.gen_text(0xD0C2, 0, n), max(n, 1))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_parity_sizes_lowentropy(svc, orc, n):
+    assert_parity(svc, orc, orc.gen_lowentropy(0xD0C5, 1000, n), max(n, 1))
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 4097, 32768, 100001, 1 << 20])
+def test_parity_sizes_random(svc, orc, n):
+    assert_parity(svc, orc, orc.java_random_bytes(42, n), max(n, 1))
+
+
+@pytest.mark.parametrize("n,bb", [(10 * 65536, 65536), (10 * 65536 + 777, 65536), (5 * 100000 + 1, 100000),
+                                  (7 * 4096 + 5, 4096), (40 * 1000, 1000), (3 * 333 + 1, 333), (64, 1), (1 << 21, 1 << 20),
+                                  (33 * 32768, 8 * 32768), (9 * 49152 + 100, 49152)])
+def test_parity_multi_block_ragged(svc, orc, n, bb):
+    # several chunks with a short last chunk, chunk sizes that are not multiples of 16 or of the segment
+    rng = np.random.default_rng(n + bb)
+    parts = [orc.gen_text(1, 0, n // 3), orc.gen_lowentropy(2, 0, n // 3), orc.java_random_bytes(3, n - 2 * (n // 3))]
+    data = np.concatenate(parts)
+    rng.shuffle(data[: n // 2])
+    assert_parity(svc, orc, data, bb)
+
+
+def _fib_data(depth, seed):
+    fib = [1, 1]
+    while len(fib) < depth + 1:
+        fib.append(fib[-1] + fib[-2])
+    data = np.repeat(np.arange(40, 40 + len(fib), dtype=np.uint8), fib)
+    np.random.default_rng(seed).shuffle(data)
+    return data
+
+
+@pytest.mark.parametrize("depth", [12, 16, 17, 20, 26, 27, 30])
+def test_parity_long_codes(svc, orc, depth):
+    # maxlen = depth: crosses the reference's 10-bit table, our 11-bit table, the G=4 (<=16), G=2 (<=26)
+    # and wide (<=32) encode paths
+    data = _fib_data(depth, depth)
+    lens, _ = orc.build_canonical_codes(orc.histogram(data))
+    assert lens.max() == depth
+    assert_parity(svc, orc, data, data.size)
+    if data.size > 200000:
+        assert_parity(svc, orc, data[: (data.size // 3) * 3], data.size // 3)
+
+
+def test_decode_errors_match_reference_semantics(pkg, svc, orc):
+    lens = np.zeros(256, np.int32)
+    lens[0x41] = 1
+    comp = np.zeros(4096, np.uint8)
+    comp[1234] = 0x04  # a set bit has no code in a single-symbol table
+    with pytest.raises(orc.DecodeError) as oe:
+        orc.decode_block(comp, lens, 20000)
+    with pytest.raises(pkg.HuffmanDecodeError) as he:
+        svc.decode_chunk(comp, lens, 20000)
+    assert he.value.position == oe.value.position == 1234 * 8 + 5
+    assert str(he.value) == str(oe.value) == "Huffman decode error at position %d" % (1234 * 8 + 5)
+    # an error beyond the requested symbols is not an error
+    assert (svc.decode_chunk(comp, lens, 1234 * 8 + 5) == 0x41).all()
+    # bits past the end of the payload read as zero (TableBasedHuffmanDecoder.java:204-208)
+    assert (svc.decode_chunk(np.zeros(1, np.uint8), lens, 5000) == orc.decode_block(np.zeros(1, np.uint8), lens, 5000)).all()
+    # truncated payload of a real stream decodes like the reference does (zero fill), no crash
+    data = orc.gen_text(5, 0, 50000)
+    pay, l = orc.encode_block(data)
+    cut = pay[: pay.size // 2]
+    try:
+        want = orc.decode_block(cut, l, data.size)
+        got = svc.decode_chunk(cut, l, data.size)
+        assert (got == want).all()
+    except orc.DecodeError as e:
+        with pytest.raises(pkg.HuffmanDecodeError) as he:
+            svc.decode_chunk(cut, l, data.size)
+        assert he.value.position == e.position
+    # empty table: error at position 0
+    with pytest.raises(pkg.HuffmanDecodeError) as he:
+        svc.decode_chunk(np.zeros(8, np.uint8), np.zeros(256, np.int32), 10)
+    assert he.value.position == 0
+    # oversubscribed table is rejected (documented deviation: the reference would decode garbage)
+    bad = np.zeros(256, np.int32)
+    bad[:3] = 1
+    with pytest.raises(pkg.DczError) as e:
+        svc.decode_chunk(np.zeros(8, np.uint8), bad, 10)
+    assert e.value.status == pkg.native.DCZ_E_BADTABLE
+
+
+def test_decode_foreign_streams(svc, orc):
+    # streams produced by the ORACLE encoder with arbitrary (non-Huffman but prefix-free, even incomplete)
+    # length tables decode identically: canonical codes from lengths are all the decoder knows
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        lens = np.zeros(256, np.int32)
+        syms = rng.choice(256, size=20, replace=False)
+        lens[syms] = rng.integers(5, 14, size=20)  # Kraft sum well below 1
+        codes, _ = orc.canonical_codes(lens)
+        data = rng.choice(syms, size=30000 + trial).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        assert (svc.decode_chunk(pay, lens, data.size) == data).all()
+
+
+def test_generators_match_oracle(pkg, svc, orc):
+    torch = _torch()
+    lib, h = pkg.lib(), svc.ctx.handle
+    for n, start in [(1, 0), (17, 4), (4096, 0), (100003, 1 << 20), (1 << 20, 12)]:
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        assert lib.dczu_fill_java_random(h, t.data_ptr(), n, 42, start, None) == 0
+        torch.cuda.synchronize()
+        assert (t.cpu().numpy() == orc.java_random_bytes(42, start + n)[start:]).all()
+        assert lib.dczu_fill_text(h, t.data_ptr(), n, 0xD0C2, start, None) == 0
+        torch.cuda.synchronize()
+        assert (t.cpu().numpy() == orc.gen_text(0xD0C2, start, n)).all()
+        assert lib.dczu_fill_lowentropy(h, t.data_ptr(), n, 0xD0C5, start, None) == 0
+        torch.cuda.synchronize()
+        assert (t.cpu().numpy() == orc.gen_lowentropy(0xD0C5, start, n)).all()
+
+
+def test_capacity_error_is_reported_per_chunk(pkg, svc, orc):
+    torch = _torch()
+    data = orc.java_random_bytes(9, 4 * 65536)
+    t = torch.from_numpy(data).cuda()
+    out = pkg.DeviceBlocks(torch.zeros(2 * 65536 + 100, dtype=torch.uint8, device="cuda"),
+                           torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda"),
+                           torch.zeros((4, 256), dtype=torch.uint8, device="cuda"),
+                           torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                           data.size, 65536)
+    svc.compress_device(t, 65536, out=out)
+    torch.cuda.synchronize()
+    st = out.status.cpu().numpy()
+    assert list(st) == [0, 0, pkg.native.DCZ_E_CAPACITY, pkg.native.DCZ_E_CAPACITY]
+    assert (out.payload[: 2 * 65536].cpu().numpy() == data[: 2 * 65536]).all()  # chunks that fit are written
+    assert not out.payload[2 * 65536:].cpu().numpy().any()                      # nothing beyond them
+
+
+# ---- BASELINE.json configs at full size: size-independent properties --------------------------------
+def _roundtrip_device(svc, t_in, bb):
+    torch = _torch()
+    n = t_in.numel()
+    blk = svc.compress_device(t_in, bb)
+    K = blk.num_chunks
+    orig = torch.full((K,), bb, dtype=torch.int32, device="cuda")
+    if n % bb:
+        orig[-1] = n % bb
+    out, status, _ = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb)
+    torch.cuda.synchronize()
+    assert int(blk.status.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
+    assert torch.equal(out[:n], t_in), "device round trip is not the identity"
+    return blk
+
+
+def test_config2_test_2mb_single_block(svc, orc, vectors):
+    data = np.full(2 * 1024 * 1024, 0x41, np.uint8)  # test_2mb.bin (sha pinned in the golden file)
+    pin = [p for p in vectors["payload_pins"] if p["name"] == "a2mib"][0]
+    assert hashlib.sha256(data.tobytes()).hexdigest() == pin["sha256"]
+    torch = _torch()
+    blk = _roundtrip_device(svc, torch.from_numpy(data).cuda(), 32 << 20)  # CLI default chunk 32 MB -> 1 block
+    assert blk.num_chunks == 1 and int(blk.total.item()) == 262144
+    assert not blk.payload[:262144].any().item()
+
+
+def test_config3_256mib_uniform_random_1mib_blocks(pkg, svc, orc):
+    torch = _torch()
+    n, bb = 256 << 20, 1 << 20
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().dczu_fill_java_random(svc.ctx.handle, t.data_ptr(), n, 42, 0, None) == 0
+    blk = _roundtrip_device(svc, t, bb)
+    # all 256 code lengths are 8 in every block, codeword(s) = s, payload == input
+    assert bool((blk.code_lengths == 8).all().item())
+    assert int(blk.total.item()) == n and torch.equal(blk.payload[:n], t)
+    # the first MiB is bit-exact against the oracle encoder too
+    first = t[:bb].cpu().numpy()
+    assert (first == orc.java_random_bytes(42, bb)).all()
+    op, ol = orc.encode_block(first)
+    assert (blk.payload[:bb].cpu().numpy() == op).all()
+
+
+@pytest.mark.parametrize("kind", ["text", "lowentropy"])
+def test_config4_5_distributions_4mib_blocks(pkg, svc, orc, kind):
+    torch = _torch()
+    n, bb = (1 << 30) + 12345, 4 << 20  # 1 GiB slice of the 8 / 64 GiB streams, ragged last block
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    fill = pkg.lib().dczu_fill_text if kind == "text" else pkg.lib().dczu_fill_lowentropy
+    seed = 0xD0C2 if kind == "text" else 0xD0C5
+    assert fill(svc.ctx.handle, t.data_ptr(), n, seed, 0, None) == 0
+    blk = _roundtrip_device(svc, t, bb)
+    # compressed sizes equal sum(hist * len) computed independently with torch on the device
+    for k in (0, blk.num_chunks // 2, blk.num_chunks - 1):
+        chunk = t[k * bb:(k + 1) * bb]
+        hist = torch.bincount(chunk.to(torch.int64), minlength=256)
+        bits = int((hist * blk.code_lengths[k].to(torch.int64)).sum().item())
+        assert int(blk.comp_size[k].item()) == (bits + 7) // 8
+    # offsets are the exclusive scan of sizes (payloads concatenated without gaps)
+    sizes = blk.comp_size.to(torch.int64)
+    assert torch.equal(blk.comp_off, torch.cumsum(sizes, 0) - sizes)
+    # first and last block bit-exact against the oracle
+    for k in (0, blk.num_chunks - 1):
+        chunk = t[k * bb:(k + 1) * bb].cpu().numpy()
+        op, ol = orc.encode_block(chunk)
+        off, sz = int(blk.comp_off[k].item()), int(blk.comp_size[k].item())
+        assert sz == op.size and (blk.code_lengths[k].cpu().numpy() == ol).all()
+        assert (blk.payload[off:off + sz].cpu().numpy() == op).all()
+    ratio = int(blk.total.item()) / n
+    assert (0.55 < ratio < 0.70) if kind == "text" else (0.125 < ratio < 0.15)
+
+
+def test_file_service_round_trip_container(svc, orc, pkg, tmp_path):
+    # CpuCompressionServiceTest.java:98-127: 3 MiB of i % 256 -> 3 chunks, progress in [0, 1], verifyIntegrity
+    data = (np.arange(3 * 1024 * 1024 + 999) % 256).astype(np.uint8)
+    src, dcz, back = tmp_path / "in.bin", tmp_path / "in.dcz", tmp_path / "back.bin"
+    src.write_bytes(data.tobytes())
+    prog = []
+    svc.compress(src, dcz, prog.append)
+    assert prog == sorted(prog) and prog[-1] == 1.0 and all(0 <= p <= 1 for p in prog) and len(prog) == 4
+    raw = dcz.read_bytes()
+    header, start = pkg.container.locate_header(raw)
+    assert start == 0 and len(header.chunks) == 4 and header.original_file_size == data.size
+    pay, sizes, offs, lens = orc.compress_blocks(data, 1 << 20)
+    assert raw[: pay.size] == pay.tobytes()
+    for k, c in enumerate(header.chunks):
+        assert (c.compressed_size, c.compressed_offset) == (int(sizes[k]), int(offs[k]))
+        assert c.code_lengths == lens[k].tolist()
+        assert c.sha256 == orc.sha256(data[k << 20:(k + 1) << 20])
+    assert len(raw) == pay.size + 68 + len("in.bin") + 572 * 4 + 8
+    svc.decompress(dcz, back)
+    assert back.read_bytes() == data.tobytes()
+    assert svc.verify_integrity(dcz)
+    corrupt = bytearray(raw)
+    corrupt[100] ^= 0x40
+    (tmp_path / "bad.dcz").write_bytes(bytes(corrupt))
+    assert not svc.verify_integrity(tmp_path / "bad.dcz")
+    with pytest.raises(IOError):
+        svc.decompress(tmp_path / "bad.dcz", back)
+    # empty file (CpuCompressionServiceTest.java:81-95): no chunks, 68 + nameLen + 8 bytes
+    (tmp_path / "empty.txt").write_bytes(b"")
+    svc.compress(tmp_path / "empty.txt", tmp_path / "empty.dcz")
+    assert (tmp_path / "empty.dcz").stat().st_size == 85
+    svc.decompress(tmp_path / "empty.dcz", back)
+    assert back.read_bytes() == b""
