@@ -238,6 +238,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     st.rflush = (st.rpos + 7u) >> 3;  // first byte whose first bit is ours
     const uint32_t col = (uint32_t)lane & 31u;
     const bool fast = (((uintptr_t)src) & 15u) == 0u;
+    // If the first owned byte is exactly the start of ring chunk 1, chunk 0 only ever holds the few leading
+    // bits that belong to the previous segment's last byte: it is never flushed, so it must be cleared by
+    // hand after the first OR phase or its bits would come back when the ring wraps.
+    const bool clear_chunk0 = (st.rflush == 16u);
 
     if (!wide) {
         const uint32_t nchunks = (slen + 1023u) >> 10;
@@ -257,6 +261,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                 encode_chunk_packed<4>(st, lut, col, cur, nb, lane);
             else
                 encode_chunk_packed<2>(st, lut, col, cur, nb, lane);
+            if (c == 0 && clear_chunk0) {
+                wave_lds_fence();
+                if (lane < 4) st.ring[lane] = 0u;
+            }
             ring_flush(st, (st.rpos >> 7) << 4, lane);
             cur = nxt;
         }
@@ -272,6 +280,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                     if (i < 4) lo |= by << (8 * i); else hi |= by << (8 * (i - 4));
                 }
             encode_chunk_wide(st, lut64, lo, hi, nb);
+            if (c == 0 && clear_chunk0) {
+                wave_lds_fence();
+                if (lane < 4) st.ring[lane] = 0u;
+            }
             ring_flush(st, (st.rpos >> 7) << 4, lane);
         }
     }

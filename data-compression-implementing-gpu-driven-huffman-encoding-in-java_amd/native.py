@@ -43,6 +43,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and dlopens it by path. If ours
+        # (DT_NEEDED libamdhip64.so.7 -> /opt/rocm) were loaded first, two runtimes would fight over the device;
+        # importing torch first makes the loader hand torch's copy to libdczhip.so by SONAME.
+        import torch  # noqa: F401
+    except ImportError:
+        pass  # no torch in the process (e.g. the JNI host): the ROCm runtime under /opt/rocm is used
     if not os.path.exists(SO_PATH):
         raise ImportError("libdczhip.so is missing at %s -- run build.py (hipcc --offload-arch=gfx950). "
                           "This package has no CPU fallback." % SO_PATH)
