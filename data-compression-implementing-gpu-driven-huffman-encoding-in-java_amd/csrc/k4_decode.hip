@@ -7,16 +7,21 @@
 // (service/gpu/GpuCompressionService.java:1340-1469); GpuCompressionService.decompress delegates to the CPU (:858).
 //
 // The frozen format stores no intra-block offsets, so parallelism inside a
-// block comes from self-synchronisation: the workgroup walks its block in windows of W subsequences
-// of 32 bytes.  Per window:
-//   A. every thread decodes its subsequence from a guessed entry bit and reports where the codeword
-//      that crosses its end finishes; guesses are replaced by the left neighbour's exit until nothing
+// block comes from self-synchronisation: the workgroup walks its block in windows of W*NS subsequences
+// of 32 bytes; every thread owns NS consecutive subsequences (its "stripe") and decodes them
+// interleaved: NS independent dependency chains per lane hide the LDS latency.  Per window:
+//   A. every subsequence is decoded from a guessed entry bit and reports where the codeword that
+//      crosses its end finishes; guesses are replaced by the left neighbour's exit until nothing
 //      changes (the first subsequence's entry is exact, so the fixed point is the true parse; Huffman
 //      streams resynchronise within a few codewords, typically 2-3 rounds);
-//   B. a workgroup scan of the symbol counts gives every thread its output offset; threads decode
-//      again, writing bytes into an LDS staging tile that is flushed with coalesced 16-byte stores.
-// The compressed window is staged once in LDS (16-byte aligned global loads, byte-swapped so that a
-// 64-bit window read gives MSB-first bits), so HBM traffic is the algorithmic C + N per block.
+//   B. a workgroup scan of the symbol counts gives every subsequence its output offset; the threads
+//      decode again, writing bytes into an LDS staging tile that is flushed with aligned 16-byte
+//      stores (a partial 16-byte tail is carried into the next flush).
+// LDS layout of the compressed window: one stripe per thread = its NS*8 MSB-first dwords + the first
+// two dwords of the next stripe (so a decode never leaves its stripe) + one pad dword: the odd stripe
+// stride makes the per-lane window fetch (one ds_read2_b32 + a 64-bit shift) bank-conflict free.
+// The next window's global loads are issued before phase B and land in registers while it runs.
+// HBM traffic is the algorithmic C + N per block.
 // Decode table: 2^11 entries (len<<8 | symbol) in LDS; longer codes take the canonical
 // first-code/count search, which for a prefix code returns exactly what the reference's
 // 10-bit-table-then-HashMap path returns.  Bits past the end of the payload read as zero
@@ -27,15 +32,20 @@ namespace dcz {
 
 constexpr int SUB_BYTES = 32;
 constexpr int SUB_BITS = SUB_BYTES * 8;
+constexpr int SUB_DW = SUB_BYTES / 4;
 constexpr int TB = 11;
-constexpr int OC = 16384;  // output staging bytes per flush
+constexpr int OC = 16384;  // output staging bytes per flush (logical)
 
-template <int W>
+template <int W, int NS>
 struct DecLds {
-    __attribute__((aligned(16))) uint32_t cbuf[W * (SUB_BYTES / 4) + 8];
-    __attribute__((aligned(16))) uint8_t outbuf[OC + 16];
+    static constexpr int NSUB = W * NS;
+    static constexpr int STRIPE = SUB_DW * NS;   // payload dwords per thread
+    static constexpr int STRIDE = STRIPE + 3;    // + 2 look-ahead dwords + 1 pad (odd => conflict-free)
+    __attribute__((aligned(16))) uint32_t cbuf[W * STRIDE + 4];
+    // logical byte i of the output tile lives at i + 4 * (i >> 6): one pad dword per 64 bytes
+    __attribute__((aligned(16))) uint32_t outbuf[(OC + OC / 16) / 4 + 16];
     uint16_t table[1 << TB];
-    uint16_t exits[W];
+    uint16_t exits[NSUB];
     uint32_t first[34];
     uint32_t cnt[34];
     uint32_t offs[34];
@@ -47,40 +57,29 @@ struct DecLds {
     int bad_table;
 };
 
-struct Sym {
-    uint32_t sym;
-    uint32_t len;  // 0 = no codeword matches
-};
+__device__ __forceinline__ uint32_t opad(uint32_t i) { return i + ((i >> 6) << 2); }
 
-template <int W>
-__device__ __forceinline__ Sym dec_lookup(const DecLds<W>& L, uint32_t pos) {
-    const uint32_t wi = pos >> 5, sh = pos & 31u;
-    const unsigned long long two = ((unsigned long long)L.cbuf[wi] << 32) | (unsigned long long)L.cbuf[wi + 1];
-    const uint32_t win = (uint32_t)((two << sh) >> 32);
-    const uint32_t e = L.table[win >> (32 - TB)];
-    Sym r;
-    if (e != 0) {
-        r.sym = e & 0xFFu;
-        r.len = e >> 8;
-        return r;
-    }
-    r.sym = 0;
-    r.len = 0;
-    const uint32_t maxlen = L.maxlen;
-    for (uint32_t l = TB + 1; l <= maxlen; l++) {
-        const uint32_t c = win >> (32u - l);
-        const uint32_t f = L.first[l];
-        if (c >= f && c - f < L.cnt[l]) {
-            r.sym = L.symtab[L.offs[l] + (c - f)];
-            r.len = l;
-            break;
-        }
-    }
-    return r;
+// Next 32 stream bits at stripe-local bit position lp (cb = this thread's stripe).
+__device__ __forceinline__ uint32_t peek32(const uint32_t* cb, uint32_t lp) {
+    const uint32_t wi = lp >> 5;
+    const unsigned long long two = ((unsigned long long)cb[wi] << 32) | (unsigned long long)cb[wi + 1];
+    return (uint32_t)((two << (lp & 31u)) >> 32);
 }
 
-template <int W>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W>& L, uint32_t& total) {
+// Long-code / invalid-code path: canonical search over lengths TB+1..maxlen on the next 32 bits.
+template <int W, int NS>
+__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS>& L, uint32_t win32) {
+    const uint32_t maxlen = L.maxlen;
+    for (uint32_t l = TB + 1; l <= maxlen; l++) {
+        const uint32_t c = win32 >> (32u - l);
+        const uint32_t f = L.first[l];
+        if (c >= f && c - f < L.cnt[l]) return (l << 8) | (uint32_t)L.symtab[L.offs[l] + (c - f)];
+    }
+    return 0;
+}
+
+template <int W, int NS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS>& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
@@ -88,15 +87,39 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W>& 
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < W / 64; w++) {
-        const uint32_t s = L.wsum[w];
-        if (w < (int)(threadIdx.x >> 6)) base += s;
-        tot += s;
+        const uint32_t sv = L.wsum[w];
+        if (w < (int)(threadIdx.x >> 6)) base += sv;
+        tot += sv;
     }
     total = tot;
     return base + inc - v;
 }
 
-template <int W>
+// Load one 16-byte chunk of the payload (virtual byte vb), zero outside [vlo, vhi), MSB-first dwords.
+__device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long long vb, unsigned long long vlo,
+                                            unsigned long long vhi) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (vb + 16 > vlo && vb < vhi) {
+        v = *reinterpret_cast<const uint4*>(vbase + vb);
+        if (vb < vlo || vb + 16 > vhi) {
+            uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long bb = vb + 4 * d + k;
+                    if (bb >= vlo && bb < vhi) m |= 0xFFu << (8 * k);
+                }
+                wds[d] &= m;
+            }
+            v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+    }
+    return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+}
+
+template <int W, int NS>
 __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
@@ -104,7 +127,9 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
                                                long long* __restrict__ d_errpos) {
-    __shared__ DecLds<W> L;
+    using LdsT = DecLds<W, NS>;
+    __shared__ LdsT L;
+    constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
 
@@ -165,7 +190,6 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         }
         L.table[idx] = (uint16_t)e;
     }
-    __syncthreads();
 
     // ---- block geometry ----
     const uint32_t orig = d_orig_size[b];
@@ -177,84 +201,144 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     const uintptr_t pay = (uintptr_t)comp + (uintptr_t)coff;
     const uint32_t skew = (uint32_t)(pay & 15u);
     const uint8_t* const vbase = reinterpret_cast<const uint8_t*>(pay - skew);
-    const unsigned long long vlo = skew;                               // first valid virtual byte
-    const unsigned long long vhi = (unsigned long long)skew + csize;   // one past the last valid virtual byte
+    const unsigned long long vlo = skew;                              // first valid virtual byte
+    const unsigned long long vhi = (unsigned long long)skew + csize;  // one past the last valid virtual byte
     (void)comp_bytes;
 
     unsigned long long ventry = 8ull * skew;  // virtual bit of the next codeword boundary
-    uint32_t produced = 0;
+    uint32_t produced = 0;                    // symbols decoded so far
+    uint32_t gpos = 0;                        // block-relative output offset of tile byte 0 (multiple of 16)
+    uint32_t ocarry = 0;                      // bytes at the front of the tile not yet stored (0..15)
     int status = DCZ_OK;
     long long errpos = 0;
+
+    uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe
+    uint8_t* const ob = reinterpret_cast<uint8_t*>(L.outbuf);
+
+    // prefetch registers for the window at wchunk0 (+ the look-ahead chunk, last thread only)
+    uint4 pre[NCH];
+    uint4 pre_m = make_uint4(0, 0, 0, 0);
+    auto prefetch = [&](unsigned long long wchunk0) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+            pre[c] = load_chunk(vbase, (wchunk0 + (unsigned long long)(tid * NCH + c)) << 4, vlo, vhi);
+        if (tid == W - 1) pre_m = load_chunk(vbase, (wchunk0 + (unsigned long long)(W * NCH)) << 4, vlo, vhi);
+    };
+    if (orig > 0) prefetch(ventry >> 7);
 
     while (produced < orig) {
         const unsigned long long wchunk0 = ventry >> 7;
         const uint32_t g0 = (uint32_t)(ventry - (wchunk0 << 7));
 
-        // stage the window (+16 bytes of look-ahead), zero outside the payload, MSB-first dwords
-        for (int c = tid; c < 2 * W + 1; c += W) {
-            const unsigned long long vb = (wchunk0 + (unsigned long long)c) << 4;  // virtual byte of this chunk
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (vb + 16 > vlo && vb < vhi) {
-                v = *reinterpret_cast<const uint4*>(vbase + vb);
-                if (vb < vlo || vb + 16 > vhi) {
-                    uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        // registers -> LDS stripes; the first two dwords are duplicated behind the previous stripe
 #pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        uint32_t m = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const unsigned long long bb = vb + 4 * d + k;
-                            if (bb >= vlo && bb < vhi) m |= 0xFFu << (8 * k);
-                        }
-                        wds[d] &= m;
-                    }
-                    v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-                }
-            }
-            uint4 sw;
-            sw.x = bswap32(v.x);
-            sw.y = bswap32(v.y);
-            sw.z = bswap32(v.z);
-            sw.w = bswap32(v.w);
-            *reinterpret_cast<uint4*>(&L.cbuf[c * 4]) = sw;
+        for (int c = 0; c < NCH; c++) {
+            cb[4 * c + 0] = pre[c].x;
+            cb[4 * c + 1] = pre[c].y;
+            cb[4 * c + 2] = pre[c].z;
+            cb[4 * c + 3] = pre[c].w;
+        }
+        if (tid > 0) {
+            cb[-3] = pre[0].x;  // previous stripe's look-ahead slots [STRIPE, STRIPE + 2)
+            cb[-2] = pre[0].y;
+        }
+        if (tid == W - 1) {
+            cb[LdsT::STRIPE] = pre_m.x;
+            cb[LdsT::STRIPE + 1] = pre_m.y;
         }
         __syncthreads();
 
-        // ---- phase A: self-synchronisation ----
-        const uint32_t limit = (uint32_t)(tid + 1) * SUB_BITS;
-        uint32_t g = (tid == 0) ? g0 : 0u;
-        uint32_t x = 0, nsym = 0;
-        bool bad = false;
-        bool need = true;
+        // ---- phase A: self-synchronisation (positions are stripe-local bit offsets) ----
+        uint32_t g[NS], x[NS], nsym[NS];
+        bool bad[NS], need[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            g[s] = 0;
+            x[s] = 0;
+            nsym[s] = 0;
+            bad[s] = false;
+            need[s] = true;
+        }
+        if (tid == 0) g[0] = g0;
+        const uint32_t q0 = (uint32_t)tid * NS;  // first subsequence of this thread
         while (true) {
-            if (need) {
-                uint32_t pos = (uint32_t)tid * SUB_BITS + g;
-                nsym = 0;
-                bad = false;
-                while (pos < limit) {
-                    const Sym s = dec_lookup<W>(L, pos);
-                    if (s.len == 0) {
-                        bad = true;
-                        break;
-                    }
-                    pos += s.len;
-                    nsym++;
+            // Branch-free inner loop: all NS window fetches are issued back to back, then all table reads, then
+            // predicated updates.  A finished stream keeps re-reading its last position (always inside its
+            // stripe + look-ahead) with len forced to 0.
+            uint32_t pos[NS];
+            bool act[NS];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                pos[s] = (uint32_t)s * SUB_BITS + g[s];
+                act[s] = need[s] && pos[s] < (uint32_t)(s + 1) * SUB_BITS;
+                if (need[s]) {
+                    nsym[s] = 0;
+                    bad[s] = false;
                 }
-                x = bad ? 0u : pos - limit;
+                if (!need[s]) pos[s] = 0;
+                any |= act[s];
             }
-            L.exits[tid] = (uint16_t)x;
+            while (any) {
+                uint32_t w32[NS], e[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) w32[s] = peek32(cb, pos[s]);
+#pragma unroll
+                for (int s = 0; s < NS; s++) e[s] = L.table[w32[s] >> (32 - TB)];
+                bool slow = false;
+#pragma unroll
+                for (int s = 0; s < NS; s++) slow |= (act[s] && e[s] == 0);
+                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {  // wave-uniform, rare: codes longer than TB bits
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                        if (act[s] && e[s] == 0) e[s] = slow_lookup<W, NS>(L, w32[s]);
+                }
+                any = false;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const bool ok = act[s] && e[s] != 0;
+                    bad[s] = bad[s] || (act[s] && e[s] == 0);
+                    pos[s] += ok ? (e[s] >> 8) : 0u;
+                    nsym[s] += ok ? 1u : 0u;
+                    act[s] = ok && pos[s] < (uint32_t)(s + 1) * SUB_BITS;
+                    any |= act[s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (need[s]) x[s] = bad[s] ? 0u : pos[s] - (uint32_t)(s + 1) * SUB_BITS;  // final pos >= limit
+#pragma unroll
+            for (int s = 0; s < NS; s++) L.exits[q0 + s] = (uint16_t)x[s];
             __syncthreads();
-            const uint32_t ng = (tid == 0) ? g0 : (uint32_t)L.exits[tid - 1];
-            need = (ng != g);
-            g = ng;
-            if (!__syncthreads_or(need)) break;
+            bool anyneed = false;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const uint32_t q = q0 + s;
+                const uint32_t ng = (q == 0) ? g0 : (uint32_t)L.exits[q - 1];
+                need[s] = (ng != g[s]);
+                g[s] = ng;
+                anyneed |= need[s];
+            }
+            if (!__syncthreads_or(anyneed)) break;
         }
 
         // ---- offsets, errors ----
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) tsum += nsym[s];
         uint32_t tw = 0;
-        const uint32_t o = block_exclusive_scan<W>(nsym, L, tw);
+        const uint32_t o = block_exclusive_scan<W, NS>(tsum, L, tw);
         const uint32_t remaining = orig - produced;
-        if (bad) atomicMin(&L.err_idx, o + nsym);
+        {
+            uint32_t oo = o;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                if (bad[s]) atomicMin(&L.err_idx, oo + nsym[s]);
+                oo += nsym[s];
+            }
+        }
+        const unsigned long long next_ventry =
+            (wchunk0 << 7) + (unsigned long long)LdsT::NSUB * SUB_BITS + (unsigned long long)L.exits[LdsT::NSUB - 1];
         __syncthreads();
         const uint32_t err_idx = L.err_idx;
         if (err_idx < remaining) {
@@ -263,41 +347,87 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             break;
         }
         const uint32_t lim = (tw < remaining) ? tw : remaining;
+        const bool more = produced + lim < orig;
+        if (more) prefetch(next_ventry >> 7);  // lands in registers while phase B runs
 
-        // ---- phase B: decode into the staging tile, flush coalesced ----
-        uint32_t k = 0;
-        uint32_t bpos = (uint32_t)tid * SUB_BITS + g;
-        for (uint32_t cb = 0; cb < lim;) {
-            const uint32_t gstart = produced + cb;
-            const uint32_t a = gstart & 15u;
-            uint32_t cc = lim - cb;
-            if (cc > (uint32_t)OC - a) cc = (uint32_t)OC - a;
-            const uint32_t cend = cb + cc;
-            while (k < nsym && o + k < cend) {
-                const Sym s = dec_lookup<W>(L, bpos);
-                L.outbuf[a + (o + k - cb)] = (uint8_t)s.sym;
-                bpos += s.len;
-                k++;
+        // ---- phase B: decode into the staging tile, flush aligned 16-byte units ----
+        // per stream: pos = stripe-local bit position, oi = tile-logical byte index of its next symbol relative
+        // to cbase (grows by 1 per symbol), rem = symbols left to emit
+        uint32_t pos[NS], oi[NS], rem[NS];
+        {
+            uint32_t oo = o;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const uint32_t avail_out = (oo < lim) ? lim - oo : 0u;  // symbols of this stream inside the block
+                rem[s] = nsym[s] < avail_out ? nsym[s] : avail_out;
+                oi[s] = oo;
+                oo += nsym[s];
+                pos[s] = (nsym[s] > 0) ? (uint32_t)s * SUB_BITS + g[s] : 0u;
             }
-            __syncthreads();
-            uint8_t* const dst = oblk + (gstart - a);
-            const uint32_t nunits = (a + cc + 15u) >> 4;
-            for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
-                const uint32_t lo = u << 4;
-                if (out_aligned && lo >= a && lo + 16u <= a + cc) {
-                    *reinterpret_cast<uint4*>(dst + lo) = *reinterpret_cast<const uint4*>(&L.outbuf[lo]);
-                } else {
-                    for (uint32_t q = 0; q < 16u; q++) {
-                        const uint32_t i = lo + q;
-                        if (i >= a && i < a + cc) dst[i] = L.outbuf[i];
-                    }
+        }
+        for (uint32_t cbase = 0; cbase < lim;) {
+            uint32_t cc = lim - cbase;
+            if (cc > (uint32_t)OC - ocarry) cc = (uint32_t)OC - ocarry;
+            const uint32_t cend = cbase + cc;
+            const uint32_t tshift = ocarry - cbase;  // tile index = window symbol index + tshift
+            bool act[NS];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                act[s] = rem[s] > 0 && oi[s] < cend;
+                any |= act[s];
+            }
+            while (any) {
+                uint32_t w32[NS], e[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) w32[s] = peek32(cb, pos[s]);
+#pragma unroll
+                for (int s = 0; s < NS; s++) e[s] = L.table[w32[s] >> (32 - TB)];
+                bool slow = false;
+#pragma unroll
+                for (int s = 0; s < NS; s++) slow |= (act[s] && e[s] == 0);
+                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                        if (act[s] && e[s] == 0) e[s] = slow_lookup<W, NS>(L, w32[s]);
+                }
+                any = false;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    if (act[s]) ob[opad(oi[s] + tshift)] = (uint8_t)e[s];
+                    pos[s] += act[s] ? (e[s] >> 8) : 0u;
+                    oi[s] += act[s] ? 1u : 0u;
+                    rem[s] -= act[s] ? 1u : 0u;
+                    act[s] = rem[s] > 0 && oi[s] < cend;
+                    any |= act[s];
                 }
             }
             __syncthreads();
-            cb = cend;
+            const uint32_t total = ocarry + cc;
+            const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
+            const uint32_t full = last ? total : (total & ~15u);
+            uint8_t* const dst = oblk + gpos;
+            const uint32_t nunits = (full + 15u) >> 4;
+            for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
+                const uint32_t lo = u << 4;
+                if (out_aligned && lo + 16u <= full) {
+                    const uint32_t* src = &L.outbuf[(lo >> 2) + (lo >> 6)];  // a unit never straddles a pad
+                    *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
+                } else {
+                    for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[opad(i)];
+                }
+            }
+            const uint32_t tail = total - full;  // < 16
+            uint8_t tv = 0;
+            if ((uint32_t)tid < tail) tv = ob[opad(full + tid)];
+            __syncthreads();
+            if ((uint32_t)tid < tail) ob[opad((uint32_t)tid)] = tv;
+            gpos += full;
+            ocarry = tail;
+            cbase = cend;
         }
         produced += lim;
-        ventry = (wchunk0 << 7) + (unsigned long long)W * SUB_BITS + (unsigned long long)L.exits[W - 1];
+        ventry = next_ventry;
         __syncthreads();
     }
 
@@ -314,10 +444,10 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (K >= 1024) {
-        hipLaunchKernelGGL(k4_decode<256>, dim3(K), dim3(256), 0, s, d_comp, comp_bytes, off, d_comp_size, d_orig_size,
-                           d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<256, 2>), dim3(K), dim3(256), 0, s, d_comp, comp_bytes, off, d_comp_size,
+                           d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
-        hipLaunchKernelGGL(k4_decode<1024>, dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
+        hipLaunchKernelGGL((k4_decode<1024, 1>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     }
 }
