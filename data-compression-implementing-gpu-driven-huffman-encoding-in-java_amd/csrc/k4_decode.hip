@@ -19,7 +19,10 @@
 //      stores (a partial 16-byte tail is carried into the next flush).
 // LDS layout of the compressed window: one stripe per thread = its NS*8 MSB-first dwords + the first
 // two dwords of the next stripe (so a decode never leaves its stripe) + one pad dword: the odd stripe
-// stride makes the per-lane window fetch (one ds_read2_b32 + a 64-bit shift) bank-conflict free.
+// stride makes the per-lane window fetch bank-conflict free.  Dwords are stored in DESCENDING address
+// order and streams track a descending bit position npos = 8*top + 31 - pos, so the fetch is
+//   addr = (npos >> 3) & ~3;  {lo,hi} = ds_read2_b32(addr);  bits = {hi,lo} >> ((npos & 31) + k)
+// i.e. two VALU for the address and no register swap for the 64-bit shift.
 // The next window's global loads are issued before phase B and land in registers while it runs.
 // HBM traffic is the algorithmic C + N per block.
 // Decode table: 2^11 entries (len<<8 | symbol) in LDS; longer codes take the canonical
@@ -59,11 +62,20 @@ struct DecLds {
 
 __device__ __forceinline__ uint32_t opad(uint32_t i) { return i + ((i >> 6) << 2); }
 
-// Next 32 stream bits at stripe-local bit position lp (cb = this thread's stripe).
-__device__ __forceinline__ uint32_t peek32(const uint32_t* cb, uint32_t lp) {
-    const uint32_t wi = lp >> 5;
-    const unsigned long long two = ((unsigned long long)cb[wi] << 32) | (unsigned long long)cb[wi + 1];
-    return (uint32_t)((two << (lp & 31u)) >> 32);
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+
+// 64-bit window {dword wi, dword wi+1} for descending position npos (see the layout note above).
+__device__ __forceinline__ unsigned long long fetch64(uint32_t npos) {
+    lds_cu32* p = (lds_cu32*)(uintptr_t)((npos >> 3) & ~3u);
+    return (unsigned long long)p[0] | ((unsigned long long)p[1] << 32);
+}
+// byte offset into the u16 table of the TB-bit window at npos
+__device__ __forceinline__ uint32_t table_off(unsigned long long two, uint32_t npos) {
+    return (uint32_t)(two >> ((npos & 31u) + (uint32_t)(32 - TB))) & (uint32_t)(((1 << TB) - 1) << 1);
+}
+// next 32 stream bits at npos (slow path only)
+__device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t npos) {
+    return (uint32_t)(two >> ((npos & 31u) + 1u));
 }
 
 // Long-code / invalid-code path: canonical search over lengths TB+1..maxlen on the next 32 bits.
@@ -212,8 +224,13 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     int status = DCZ_OK;
     long long errpos = 0;
 
-    uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe
+    uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe (descending)
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.outbuf);
+    // descending-position origin: logical dword j of the stripe lives at cb[STRIPE + 1 - j]
+    const uint32_t top_addr =
+        (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
+    const uint32_t nbase = 8u * top_addr + 31u;  // npos = nbase - pos
+    const uint32_t tbl_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.table[0]));
 
     // prefetch registers for the window at wchunk0 (+ the look-ahead chunk, last thread only)
     uint4 pre[NCH];
@@ -230,21 +247,22 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         const unsigned long long wchunk0 = ventry >> 7;
         const uint32_t g0 = (uint32_t)(ventry - (wchunk0 << 7));
 
-        // registers -> LDS stripes; the first two dwords are duplicated behind the previous stripe
+        // registers -> LDS stripes (descending dword order); the first two dwords are duplicated at the low
+        // end of the previous stripe as its look-ahead
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            cb[4 * c + 0] = pre[c].x;
-            cb[4 * c + 1] = pre[c].y;
-            cb[4 * c + 2] = pre[c].z;
-            cb[4 * c + 3] = pre[c].w;
+            cb[LdsT::STRIPE + 1 - (4 * c + 0)] = pre[c].x;
+            cb[LdsT::STRIPE + 1 - (4 * c + 1)] = pre[c].y;
+            cb[LdsT::STRIPE + 1 - (4 * c + 2)] = pre[c].z;
+            cb[LdsT::STRIPE + 1 - (4 * c + 3)] = pre[c].w;
         }
         if (tid > 0) {
-            cb[-3] = pre[0].x;  // previous stripe's look-ahead slots [STRIPE, STRIPE + 2)
-            cb[-2] = pre[0].y;
+            cb[1 - LdsT::STRIDE] = pre[0].x;  // previous stripe, logical dword STRIPE
+            cb[0 - LdsT::STRIDE] = pre[0].y;  // previous stripe, logical dword STRIPE + 1
         }
         if (tid == W - 1) {
-            cb[LdsT::STRIPE] = pre_m.x;
-            cb[LdsT::STRIPE + 1] = pre_m.y;
+            cb[1] = pre_m.x;
+            cb[0] = pre_m.y;
         }
         __syncthreads();
 
@@ -262,51 +280,58 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         if (tid == 0) g[0] = g0;
         const uint32_t q0 = (uint32_t)tid * NS;  // first subsequence of this thread
         while (true) {
-            // Branch-free inner loop: all NS window fetches are issued back to back, then all table reads, then
-            // predicated updates.  A finished stream keeps re-reading its last position (always inside its
-            // stripe + look-ahead) with len forced to 0.
-            uint32_t pos[NS];
-            bool act[NS];
+            // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
+            // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are
+            // issued back to back, then all table reads, then predicated updates; errors and codes longer than TB
+            // bits are handled inside a wave-uniform, rarely taken branch.
+            uint32_t np[NS], nl[NS];
             bool any = false;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                pos[s] = (uint32_t)s * SUB_BITS + g[s];
-                act[s] = need[s] && pos[s] < (uint32_t)(s + 1) * SUB_BITS;
+                const uint32_t start = (uint32_t)s * SUB_BITS + g[s];
+                np[s] = nbase - (need[s] ? start : 0u);
+                nl[s] = need[s] ? nbase - (uint32_t)(s + 1) * SUB_BITS : 0xFFFFFFFFu;
                 if (need[s]) {
                     nsym[s] = 0;
                     bad[s] = false;
                 }
-                if (!need[s]) pos[s] = 0;
-                any |= act[s];
+                any |= np[s] > nl[s];
             }
             while (any) {
-                uint32_t w32[NS], e[NS];
+                unsigned long long two[NS];
+                uint32_t e[NS];
 #pragma unroll
-                for (int s = 0; s < NS; s++) w32[s] = peek32(cb, pos[s]);
+                for (int s = 0; s < NS; s++) two[s] = fetch64(np[s]);
 #pragma unroll
-                for (int s = 0; s < NS; s++) e[s] = L.table[w32[s] >> (32 - TB)];
-                bool slow = false;
+                for (int s = 0; s < NS; s++)
+                    e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
+                                                                                         table_off(two[s], np[s]));
+                bool miss = false;
 #pragma unroll
-                for (int s = 0; s < NS; s++) slow |= (act[s] && e[s] == 0);
-                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {  // wave-uniform, rare: codes longer than TB bits
+                for (int s = 0; s < NS; s++) miss |= (e[s] == 0 && np[s] > nl[s]);
+                if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (act[s] && e[s] == 0) e[s] = slow_lookup<W, NS>(L, w32[s]);
+                        if (e[s] == 0 && np[s] > nl[s]) {
+                            e[s] = slow_lookup<W, NS>(L, window32(two[s], np[s]));
+                            if (e[s] == 0) {  // no codeword matches: stop this stream
+                                bad[s] = true;
+                                nl[s] = 0xFFFFFFFFu;
+                            }
+                        }
                 }
                 any = false;
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
-                    const bool ok = act[s] && e[s] != 0;
-                    bad[s] = bad[s] || (act[s] && e[s] == 0);
-                    pos[s] += ok ? (e[s] >> 8) : 0u;
-                    nsym[s] += ok ? 1u : 0u;
-                    act[s] = ok && pos[s] < (uint32_t)(s + 1) * SUB_BITS;
-                    any |= act[s];
+                    const bool a = np[s] > nl[s];
+                    np[s] -= a ? (e[s] >> 8) : 0u;
+                    nsym[s] += a ? 1u : 0u;
+                    any |= np[s] > nl[s];
                 }
             }
 #pragma unroll
-            for (int s = 0; s < NS; s++)
-                if (need[s]) x[s] = bad[s] ? 0u : pos[s] - (uint32_t)(s + 1) * SUB_BITS;  // final pos >= limit
+            for (int s = 0; s < NS; s++)  // final pos >= limit (or the start itself when it lies past the limit)
+                if (need[s]) x[s] = bad[s] ? 0u : (nbase - np[s]) - (uint32_t)(s + 1) * SUB_BITS;
 #pragma unroll
             for (int s = 0; s < NS; s++) L.exits[q0 + s] = (uint16_t)x[s];
             __syncthreads();
@@ -351,18 +376,19 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         if (more) prefetch(next_ventry >> 7);  // lands in registers while phase B runs
 
         // ---- phase B: decode into the staging tile, flush aligned 16-byte units ----
-        // per stream: pos = stripe-local bit position, oi = tile-logical byte index of its next symbol relative
-        // to cbase (grows by 1 per symbol), rem = symbols left to emit
-        uint32_t pos[NS], oi[NS], rem[NS];
+        // per stream: np = descending bit position, oi = window symbol index of its next symbol, oe = one past its
+        // last symbol inside the block
+        uint32_t np[NS], oi[NS], oe[NS];
         {
             uint32_t oo = o;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                const uint32_t avail_out = (oo < lim) ? lim - oo : 0u;  // symbols of this stream inside the block
-                rem[s] = nsym[s] < avail_out ? nsym[s] : avail_out;
+                const uint32_t end = oo + nsym[s];
                 oi[s] = oo;
-                oo += nsym[s];
-                pos[s] = (nsym[s] > 0) ? (uint32_t)s * SUB_BITS + g[s] : 0u;
+                oe[s] = end < lim ? end : lim;
+                if (oe[s] < oi[s]) oe[s] = oi[s];
+                np[s] = nbase - ((nsym[s] > 0) ? (uint32_t)s * SUB_BITS + g[s] : 0u);
+                oo = end;
             }
         }
         for (uint32_t cbase = 0; cbase < lim;) {
@@ -370,36 +396,38 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             if (cc > (uint32_t)OC - ocarry) cc = (uint32_t)OC - ocarry;
             const uint32_t cend = cbase + cc;
             const uint32_t tshift = ocarry - cbase;  // tile index = window symbol index + tshift
-            bool act[NS];
+            uint32_t ce[NS];                         // this chunk's end for each stream
             bool any = false;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                act[s] = rem[s] > 0 && oi[s] < cend;
-                any |= act[s];
+                ce[s] = oe[s] < cend ? oe[s] : cend;
+                any |= oi[s] < ce[s];
             }
             while (any) {
-                uint32_t w32[NS], e[NS];
+                unsigned long long two[NS];
+                uint32_t e[NS];
 #pragma unroll
-                for (int s = 0; s < NS; s++) w32[s] = peek32(cb, pos[s]);
+                for (int s = 0; s < NS; s++) two[s] = fetch64(np[s]);
 #pragma unroll
-                for (int s = 0; s < NS; s++) e[s] = L.table[w32[s] >> (32 - TB)];
-                bool slow = false;
+                for (int s = 0; s < NS; s++)
+                    e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
+                                                                                         table_off(two[s], np[s]));
+                bool miss = false;
 #pragma unroll
-                for (int s = 0; s < NS; s++) slow |= (act[s] && e[s] == 0);
-                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
+                for (int s = 0; s < NS; s++) miss |= (e[s] == 0 && oi[s] < ce[s]);
+                if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (act[s] && e[s] == 0) e[s] = slow_lookup<W, NS>(L, w32[s]);
+                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS>(L, window32(two[s], np[s]));
                 }
                 any = false;
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
-                    if (act[s]) ob[opad(oi[s] + tshift)] = (uint8_t)e[s];
-                    pos[s] += act[s] ? (e[s] >> 8) : 0u;
-                    oi[s] += act[s] ? 1u : 0u;
-                    rem[s] -= act[s] ? 1u : 0u;
-                    act[s] = rem[s] > 0 && oi[s] < cend;
-                    any |= act[s];
+                    const bool a = oi[s] < ce[s];
+                    if (a) ob[opad(oi[s] + tshift)] = (uint8_t)e[s];
+                    np[s] -= a ? (e[s] >> 8) : 0u;
+                    oi[s] += a ? 1u : 0u;
+                    any |= oi[s] < ce[s];
                 }
             }
             __syncthreads();
