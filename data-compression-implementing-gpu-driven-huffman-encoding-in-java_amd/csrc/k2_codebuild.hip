@@ -16,17 +16,20 @@
 // internal nodes (symbol -1 -> 0) sort before leaves of equal weight and two internal nodes of equal
 // weight compare EQUAL, exactly as compareTo does.  The heap is stored shifted by one slot so that
 // the two children of slot k sit in one aligned 16-byte pair (a single ds_read_b128 per level).
-// This kernel is latency-bound (a few hundred heap operations); it runs K blocks concurrently.
+// This kernel is latency-bound (a few hundred dependent heap operations per block), so it runs ONE WAVE per
+// block: 20+ blocks are resident per CU and the serial heap walks of different blocks overlap.
 #include "dcz_internal.h"
 
 namespace dcz {
 
+constexpr int K2_T = 64;  // threads per block-workgroup (one wave)
+
 struct CodeLds {
     __attribute__((aligned(16))) unsigned long long heap[260];  // slot i+1 holds PriorityQueue.queue[i]
     unsigned long long hist[256];
-    unsigned long long wsum[8];
     uint32_t cnt[34];
     uint32_t first[34];
+    uint32_t code[256];
     uint16_t parent[512];
     uint8_t len[256];
     int nsym;
@@ -75,23 +78,27 @@ __device__ __forceinline__ unsigned long long heap_poll(unsigned long long* q, i
     return result;
 }
 
-// Code lengths for hist[] in LDS (L.hist) -> L.len, L.maxlen, L.nsym.  All 256 threads call this.
+// Code lengths for hist[] in LDS (L.hist) -> L.len, L.maxlen, L.nsym.  All K2_T threads call this.
 __device__ void build_lengths(CodeLds& L) {
     const int tid = (int)threadIdx.x;
-    const unsigned long long f = L.hist[tid];
-    const int nsym = __syncthreads_count(f > 0);
+    int mine = 0;
+    for (int s = tid; s < 256; s += K2_T) {
+        mine += (L.hist[s] > 0) ? 1 : 0;
+        L.len[s] = 0;
+    }
+    const int nsym = (int)wave_reduce_add_u32((uint32_t)mine);
     if (tid == 0) {
         L.nsym = nsym;
         L.maxlen = 0;
     }
-    L.len[tid] = 0;
     __syncthreads();
     if (nsym == 0) return;  // core/CanonicalHuffman.java:30-32
     if (nsym == 1) {        // core/CanonicalHuffman.java:35-45: the single symbol gets length 1, code 0
-        if (f > 0) {
-            L.len[tid] = 1;
-            L.maxlen = 1;
-        }
+        for (int s = tid; s < 256; s += K2_T)
+            if (L.hist[s] > 0) {
+                L.len[s] = 1;
+                L.maxlen = 1;
+            }
         __syncthreads();
         return;
     }
@@ -115,28 +122,31 @@ __device__ void build_lengths(CodeLds& L) {
     }
     __syncthreads();
     // core/CanonicalHuffman.java:85-92 extractLengths: depth of each leaf
-    int d = 0;
-    if (f > 0) {
-        int x = tid;
-        while (true) {
-            const int p = L.parent[x];
-            if (p == 0xFFFF) break;
-            x = p;
-            d++;
+    for (int s = tid; s < 256; s += K2_T) {
+        if (L.hist[s] > 0) {
+            int d = 0, x = s;
+            while (true) {
+                const int p = L.parent[x];
+                if (p == 0xFFFF) break;
+                x = p;
+                d++;
+            }
+            L.len[s] = (uint8_t)(d > 255 ? 255 : d);
+            atomicMax(&L.maxlen, d);
         }
-        L.len[tid] = (uint8_t)(d > 255 ? 255 : d);
-        atomicMax(&L.maxlen, d);
     }
     __syncthreads();
 }
 
-// core/CanonicalHuffman.java:99-132 generateCanonicalCodes, from L.len (all <= 32). Returns this thread's code.
-__device__ uint32_t canonical_code(CodeLds& L) {
+// core/CanonicalHuffman.java:99-132 generateCanonicalCodes, from L.len (all <= 32) -> L.code.
+__device__ void canonical_codes(CodeLds& L) {
     const int tid = (int)threadIdx.x;
     if (tid < 34) L.cnt[tid] = 0;
     __syncthreads();
-    const int l = L.len[tid];
-    if (l > 0) atomicAdd(&L.cnt[l], 1u);
+    for (int s = tid; s < 256; s += K2_T) {
+        const int l = L.len[s];
+        if (l > 0) atomicAdd(&L.cnt[l], 1u);
+    }
     __syncthreads();
     if (tid == 0) {
         uint32_t c = 0;
@@ -147,30 +157,35 @@ __device__ uint32_t canonical_code(CodeLds& L) {
         }
     }
     __syncthreads();
-    uint32_t code = 0;
-    if (l > 0) {  // core/CanonicalHuffman.java:123-129: ascending symbol order within a length
-        uint32_t rank = 0;
-        for (int s = 0; s < tid; s++) rank += (L.len[s] == l) ? 1u : 0u;
-        code = L.first[l] + rank;
+    // core/CanonicalHuffman.java:123-129: ascending symbol order within a length.  Symbols are visited in chunks of
+    // K2_T consecutive symbols; a ballot per distinct length ranks the lanes of a chunk, L.first[] carries over.
+    for (int base = 0; base < 256; base += K2_T) {
+        const int sym = base + tid;
+        const uint32_t l = L.len[sym];
+        uint32_t code = 0;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(l > 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane((int)l, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(l == ll);
+            if (l == ll) code = L.first[ll] + (uint32_t)__builtin_popcountll(same & ((1ull << tid) - 1ull));
+            __syncthreads();
+            if (tid == leader) L.first[ll] += (uint32_t)__builtin_popcountll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+        L.code[sym] = code;
     }
-    return code;
+    __syncthreads();
 }
 
-__device__ __forceinline__ unsigned long long block_reduce_add_u64(unsigned long long v, CodeLds& L) {
-    v = wave_reduce_add_u64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63u) == 0) L.wsum[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
-}
-
-__global__ __launch_bounds__(256) void k2_codebuild(const uint16_t* __restrict__ seg_hist,
-                                                    const long long* __restrict__ hist_in, size_t n,
-                                                    size_t block_bytes, uint32_t spb, uint32_t K,
-                                                    uint8_t* __restrict__ d_len, uint32_t* __restrict__ d_code,
-                                                    uint8_t* __restrict__ d_maxlen, uint32_t* __restrict__ d_comp_size,
-                                                    unsigned long long* __restrict__ d_seg_bitoff,
-                                                    int32_t* __restrict__ d_status) {
+__global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict__ seg_hist,
+                                                     const long long* __restrict__ hist_in, size_t n,
+                                                     size_t block_bytes, uint32_t spb, uint32_t K,
+                                                     uint8_t* __restrict__ d_len, uint32_t* __restrict__ d_code,
+                                                     uint8_t* __restrict__ d_maxlen, uint32_t* __restrict__ d_comp_size,
+                                                     unsigned long long* __restrict__ d_seg_bitoff,
+                                                     int32_t* __restrict__ d_status) {
     __shared__ CodeLds L;
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
@@ -184,36 +199,50 @@ __global__ __launch_bounds__(256) void k2_codebuild(const uint16_t* __restrict__
     }
     const uint16_t* rows = seg_hist ? seg_hist + (uint64_t)b * spb * 256u : nullptr;
 
-    unsigned long long f = 0;
+    // block histogram = sum of its segment rows (lane t owns bins 4t..4t+3: one 8-byte load per row)
     if (seg_hist) {
-        for (uint32_t j = 0; j < nsb; j++) f += rows[(uint64_t)j * 256u + tid];
+        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        for (uint32_t j = 0; j < nsb; j++) {
+            const uint2 v = *reinterpret_cast<const uint2*>(rows + (uint64_t)j * 256u + 4u * (uint32_t)tid);
+            f0 += v.x & 0xFFFFu;
+            f1 += v.x >> 16;
+            f2 += v.y & 0xFFFFu;
+            f3 += v.y >> 16;
+        }
+        L.hist[4 * tid + 0] = f0;
+        L.hist[4 * tid + 1] = f1;
+        L.hist[4 * tid + 2] = f2;
+        L.hist[4 * tid + 3] = f3;
     } else {
-        f = (unsigned long long)hist_in[(uint64_t)b * 256u + tid];
+        for (int s = tid; s < 256; s += K2_T) L.hist[s] = (unsigned long long)hist_in[(uint64_t)b * 256u + s];
     }
-    L.hist[tid] = f;
     __syncthreads();
 
     build_lengths(L);
     const int maxlen = L.maxlen;
     const bool too_long = maxlen > 32;  // core/CanonicalHuffman.java:102-106 would throw
-    if (too_long) L.len[tid] = 0;
+    if (too_long)
+        for (int s = tid; s < 256; s += K2_T) L.len[s] = 0;
     __syncthreads();
-    const uint32_t code = canonical_code(L);
-    const uint32_t l = L.len[tid];
-    d_len[(uint64_t)b * 256u + tid] = (uint8_t)l;
-    d_code[(uint64_t)b * 256u + tid] = code;
-
-    const unsigned long long bits = block_reduce_add_u64(f * (unsigned long long)l, L);
+    canonical_codes(L);
+    unsigned long long bits = 0;
+    for (int s = tid; s < 256; s += K2_T) {
+        const uint32_t l = L.len[s];
+        d_len[(uint64_t)b * 256u + s] = (uint8_t)l;
+        d_code[(uint64_t)b * 256u + s] = L.code[s];
+        bits += L.hist[s] * (unsigned long long)l;
+    }
+    bits = wave_reduce_add_u64(bits);
     if (tid == 0) {
         d_maxlen[b] = (uint8_t)(too_long ? 0 : maxlen);
         d_comp_size[b] = too_long ? 0u : (uint32_t)((bits + 7) >> 3);
         d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
     }
 
-    // per-segment bit offsets inside the block: exclusive scan of bits(segment)
+    // per-segment bit offsets inside the block: exclusive scan of bits(segment) = sum_s seg_hist[seg][s] * len[s]
     if (seg_hist && d_seg_bitoff) {
         unsigned long long carry = 0;
-        for (uint32_t c0 = 0; c0 < spb; c0 += 256) {
+        for (uint32_t c0 = 0; c0 < spb; c0 += K2_T) {
             const uint32_t j = c0 + (uint32_t)tid;
             unsigned long long sb = 0;
             if (j < nsb) {
@@ -225,20 +254,14 @@ __global__ __launch_bounds__(256) void k2_codebuild(const uint16_t* __restrict__
                 }
                 sb = acc;
             }
-            // block-wide exclusive scan of sb
             unsigned long long inc = sb;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned long long t = __shfl_up(inc, o, 64);
-                if ((tid & 63) >= o) inc += t;
+                if (tid >= o) inc += t;
             }
-            __syncthreads();
-            if ((tid & 63) == 63) L.wsum[tid >> 6] = inc;
-            __syncthreads();
-            unsigned long long wbase = 0;
-            for (int w = 0; w < (tid >> 6); w++) wbase += L.wsum[w];
-            const unsigned long long tot = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
-            if (j < spb) d_seg_bitoff[(uint64_t)b * spb + j] = carry + wbase + inc - sb;
+            const unsigned long long tot = __shfl(inc, 63, 64);
+            if (j < spb) d_seg_bitoff[(uint64_t)b * spb + j] = carry + inc - sb;
             carry += tot;
         }
     }
@@ -246,17 +269,21 @@ __global__ __launch_bounds__(256) void k2_codebuild(const uint16_t* __restrict__
 }
 
 // CanonicalHuffman.generateCanonicalCodesFromLengths (core/CanonicalHuffman.java:141-146) for one table.
-__global__ __launch_bounds__(256) void k2_codes_from_lengths(const int32_t* __restrict__ len32,
-                                                             uint32_t* __restrict__ d_code,
-                                                             int32_t* __restrict__ d_status) {
+__global__ __launch_bounds__(K2_T) void k2_codes_from_lengths(const int32_t* __restrict__ len32,
+                                                              uint32_t* __restrict__ d_code,
+                                                              int32_t* __restrict__ d_status) {
     __shared__ CodeLds L;
     const int tid = (int)threadIdx.x;
-    const int32_t l = len32[tid];
-    const int bad = __syncthreads_or(l < 0 || l > 32);  // core/CanonicalHuffman.java:106 would throw
-    L.len[tid] = bad ? 0 : (uint8_t)l;
+    bool mybad = false;
+    for (int s = tid; s < 256; s += K2_T) {
+        const int32_t l = len32[s];
+        mybad |= (l < 0 || l > 32);  // core/CanonicalHuffman.java:106 would throw
+    }
+    const bool bad = __builtin_amdgcn_ballot_w64(mybad) != 0ull;
+    for (int s = tid; s < 256; s += K2_T) L.len[s] = bad ? 0 : (uint8_t)len32[s];
     __syncthreads();
-    const uint32_t code = canonical_code(L);
-    d_code[tid] = bad ? 0u : code;
+    canonical_codes(L);
+    for (int s = tid; s < 256; s += K2_T) d_code[s] = bad ? 0u : L.code[s];
     if (tid == 0) d_status[0] = bad ? DCZ_E_BADTABLE : DCZ_OK;
 }
 
@@ -302,13 +329,13 @@ void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t
                       uint32_t segs_per_block, uint32_t K, uint8_t* d_len, uint32_t* d_code, uint8_t* d_maxlen,
                       uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s) {
     if (K == 0) return;
-    hipLaunchKernelGGL(k2_codebuild, dim3(K), dim3(256), 0, s, seg_hist, reinterpret_cast<const long long*>(d_hist_in),
+    hipLaunchKernelGGL(k2_codebuild, dim3(K), dim3(K2_T), 0, s, seg_hist, reinterpret_cast<const long long*>(d_hist_in),
                        n, block_bytes, segs_per_block, K, d_len, d_code, d_maxlen, d_comp_size,
                        reinterpret_cast<unsigned long long*>(d_seg_bitoff), d_status);
 }
 
 void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s) {
-    hipLaunchKernelGGL(k2_codes_from_lengths, dim3(1), dim3(256), 0, s, d_len32, d_code, d_status);
+    hipLaunchKernelGGL(k2_codes_from_lengths, dim3(1), dim3(K2_T), 0, s, d_len32, d_code, d_status);
 }
 
 void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total, size_t out_cap,

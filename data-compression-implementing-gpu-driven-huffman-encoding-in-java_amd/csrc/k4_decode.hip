@@ -36,11 +36,31 @@ namespace dcz {
 constexpr int SUB_BYTES = 32;
 constexpr int SUB_BITS = SUB_BYTES * 8;
 constexpr int SUB_DW = SUB_BYTES / 4;
-constexpr int TB = 11;
-constexpr int OC = 16384;  // output staging bytes per flush (logical)
+#ifndef DCZ_K4_TB
+#define DCZ_K4_TB 11
+#endif
+#ifndef DCZ_K4_W
+#define DCZ_K4_W 256
+#endif
+constexpr int TB = DCZ_K4_TB;
+// Tuning knobs (measured on MI355X, 8 GiB uniform random, 1 MiB blocks: NS=1/OC=8 KiB/W=256 is fastest -- more
+// resident workgroups hide LDS latency better than in-thread ILP).
+#ifndef DCZ_K4_OC
+#define DCZ_K4_OC 8192   // output staging bytes per flush, many-blocks kernel
+#endif
+#ifndef DCZ_K4_NS
+#define DCZ_K4_NS 1      // subsequences per thread, many-blocks kernel
+#endif
+#ifndef DCZ_K4S_OC
+#define DCZ_K4S_OC 16384 // few-blocks kernel (one 1024-thread workgroup per block)
+#endif
+#ifndef DCZ_K4S_NS
+#define DCZ_K4S_NS 1
+#endif
 
-template <int W, int NS>
+template <int W, int NS, int OC>
 struct DecLds {
+    static_assert(W >= 256 && W % 64 == 0, "the table build assumes at least 256 threads");
     static constexpr int NSUB = W * NS;
     static constexpr int STRIPE = SUB_DW * NS;   // payload dwords per thread
     static constexpr int STRIDE = STRIPE + 3;    // + 2 look-ahead dwords + 1 pad (odd => conflict-free)
@@ -79,8 +99,8 @@ __device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t np
 }
 
 // Long-code / invalid-code path: canonical search over lengths TB+1..maxlen on the next 32 bits.
-template <int W, int NS>
-__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS>& L, uint32_t win32) {
+template <int W, int NS, int OC>
+__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS, OC>& L, uint32_t win32) {
     const uint32_t maxlen = L.maxlen;
     for (uint32_t l = TB + 1; l <= maxlen; l++) {
         const uint32_t c = win32 >> (32u - l);
@@ -90,8 +110,8 @@ __device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS>& L, uint32_t wi
     return 0;
 }
 
-template <int W, int NS>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS>& L, uint32_t& total) {
+template <int W, int NS, int OC>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC>& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
@@ -131,7 +151,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
     return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
 }
 
-template <int W, int NS>
+template <int W, int NS, int OC>
 __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
                                                long long* __restrict__ d_errpos) {
-    using LdsT = DecLds<W, NS>;
+    using LdsT = DecLds<W, NS, OC>;
     __shared__ LdsT L;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                         if (e[s] == 0 && np[s] > nl[s]) {
-                            e[s] = slow_lookup<W, NS>(L, window32(two[s], np[s]));
+                            e[s] = slow_lookup<W, NS, OC>(L, window32(two[s], np[s]));
                             if (e[s] == 0) {  // no codeword matches: stop this stream
                                 bad[s] = true;
                                 nl[s] = 0xFFFFFFFFu;
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
         for (int s = 0; s < NS; s++) tsum += nsym[s];
         uint32_t tw = 0;
-        const uint32_t o = block_exclusive_scan<W, NS>(tsum, L, tw);
+        const uint32_t o = block_exclusive_scan<W, NS, OC>(tsum, L, tw);
         const uint32_t remaining = orig - produced;
         {
             uint32_t oo = o;
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                 if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS>(L, window32(two[s], np[s]));
+                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC>(L, window32(two[s], np[s]));
                 }
                 any = false;
 #pragma unroll
@@ -472,10 +492,10 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (K >= 1024) {
-        hipLaunchKernelGGL((k4_decode<256, 2>), dim3(K), dim3(256), 0, s, d_comp, comp_bytes, off, d_comp_size,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
-        hipLaunchKernelGGL((k4_decode<1024, 1>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
+        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     }
 }

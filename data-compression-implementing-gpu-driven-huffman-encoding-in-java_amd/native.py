@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libdczhip.so")
+SO_PATH = os.environ.get("DCZ_LIB") or os.path.join(HERE, "libdczhip.so")  # DCZ_LIB: tuning experiments only
 
 DCZ_OK = 0
 DCZ_E_INVALID = -1
