@@ -51,6 +51,12 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4_NS
 #define DCZ_K4_NS 1      // subsequences per thread, many-blocks kernel
 #endif
+#ifndef DCZ_K4_PRIV
+#define DCZ_K4_PRIV 0    // symbols a subsequence may park in LDS during phase A, many-blocks kernel (0 = off: the
+#endif                   // extra LDS costs more occupancy than the second decode costs time; measured)
+#ifndef DCZ_K4S_PRIV
+#define DCZ_K4S_PRIV 64  // few-blocks kernel: one workgroup per CU anyway, so LDS is free and parking pays
+#endif
 #ifndef DCZ_K4S_OC
 #define DCZ_K4S_OC 16384 // few-blocks kernel (one 1024-thread workgroup per block)
 #endif
@@ -58,7 +64,7 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4S_NS 1
 #endif
 
-template <int W, int NS, int OC>
+template <int W, int NS, int OC, int PV>
 struct DecLds {
     static_assert(W >= 256 && W % 64 == 0, "the table build assumes at least 256 threads");
     static constexpr int NSUB = W * NS;
@@ -67,6 +73,11 @@ struct DecLds {
     __attribute__((aligned(16))) uint32_t cbuf[W * STRIDE + 4];
     // logical byte i of the output tile lives at i + 4 * (i >> 6): one pad dword per 64 bytes
     __attribute__((aligned(16))) uint32_t outbuf[(OC + OC / 16) / 4 + 16];
+    // phase A parks the symbols of each subsequence here; after the fixed point the LAST decode of a
+    // subsequence started at its true entry, so phase B can copy them instead of decoding again
+    static constexpr int PRIV = (NS == 1) ? PV : 0;
+    static constexpr int PRIV_DW = PRIV ? PRIV / 4 + 1 : 0;  // odd dword stride: conflict-free lane-strided access
+    uint32_t priv[W * PRIV_DW + 4];
     uint16_t table[1 << TB];
     uint16_t exits[NSUB];
     uint32_t first[34];
@@ -99,8 +110,8 @@ __device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t np
 }
 
 // Long-code / invalid-code path: canonical search over lengths TB+1..maxlen on the next 32 bits.
-template <int W, int NS, int OC>
-__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS, OC>& L, uint32_t win32) {
+template <int W, int NS, int OC, int PV>
+__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV>& L, uint32_t win32) {
     const uint32_t maxlen = L.maxlen;
     for (uint32_t l = TB + 1; l <= maxlen; l++) {
         const uint32_t c = win32 >> (32u - l);
@@ -110,8 +121,39 @@ __device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS, OC>& L, uint32_
     return 0;
 }
 
-template <int W, int NS, int OC>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC>& L, uint32_t& total) {
+// Copy cnt bytes from a thread's private area (byte offset so) to logical tile byte dlog: bytes up to the next
+// tile dword, then whole dwords assembled with v_alignbyte, then the remaining bytes.
+__device__ __forceinline__ void copy_run(const uint32_t* pv, uint32_t so, uint32_t* tile, uint32_t dlog, uint32_t cnt) {
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(pv);
+    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
+    while (cnt > 0 && (dlog & 3u) != 0u) {
+        tb[opad(dlog)] = pb[so];
+        so++;
+        dlog++;
+        cnt--;
+    }
+    uint32_t q = so >> 2;
+    const uint32_t sel = so & 3u;
+    uint32_t lo = pv[q];
+    while (cnt >= 4) {
+        const uint32_t hi = pv[q + 1];  // at most one dword past the parked symbols: the stride's pad dword
+        tile[(dlog >> 2) + (dlog >> 6)] = __builtin_amdgcn_alignbyte(hi, lo, sel);
+        lo = hi;
+        q++;
+        so += 4;
+        dlog += 4;
+        cnt -= 4;
+    }
+    while (cnt > 0) {
+        tb[opad(dlog)] = pb[so];
+        so++;
+        dlog++;
+        cnt--;
+    }
+}
+
+template <int W, int NS, int OC, int PV>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC, PV>& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
@@ -151,7 +193,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
     return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
 }
 
-template <int W, int NS, int OC>
+template <int W, int NS, int OC, int PV>
 __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
@@ -159,7 +201,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
                                                long long* __restrict__ d_errpos) {
-    using LdsT = DecLds<W, NS, OC>;
+    using LdsT = DecLds<W, NS, OC, PV>;
     __shared__ LdsT L;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
@@ -237,6 +279,10 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     const unsigned long long vhi = (unsigned long long)skew + csize;  // one past the last valid virtual byte
     (void)comp_bytes;
 
+    // Park symbols only when a 32-byte subsequence is expected to hold at most ~7/8 of the private capacity
+    // (average code length from the block's own sizes); otherwise most subsequences would overflow and be
+    // decoded twice anyway.
+    const bool park = LdsT::PRIV > 0 && (unsigned long long)orig * 32ull * 8ull <= (unsigned long long)csize * 7ull * (unsigned long long)LdsT::PRIV;
     unsigned long long ventry = 8ull * skew;  // virtual bit of the next codeword boundary
     uint32_t produced = 0;                    // symbols decoded so far
     uint32_t gpos = 0;                        // block-relative output offset of tile byte 0 (multiple of 16)
@@ -246,6 +292,8 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 
     uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe (descending)
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.outbuf);
+    uint32_t* const pv = &L.priv[(uint32_t)tid * (uint32_t)LdsT::PRIV_DW];  // this thread's private symbol area
+    uint8_t* const pvb = reinterpret_cast<uint8_t*>(pv);
     // descending-position origin: logical dword j of the stripe lives at cb[STRIPE + 1 - j]
     const uint32_t top_addr =
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
@@ -333,7 +381,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                         if (e[s] == 0 && np[s] > nl[s]) {
-                            e[s] = slow_lookup<W, NS, OC>(L, window32(two[s], np[s]));
+                            e[s] = slow_lookup<W, NS, OC, PV>(L, window32(two[s], np[s]));
                             if (e[s] == 0) {  // no codeword matches: stop this stream
                                 bad[s] = true;
                                 nl[s] = 0xFFFFFFFFu;
@@ -344,6 +392,9 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     const bool a = np[s] > nl[s];
+                    if constexpr (LdsT::PRIV > 0) {
+                        if (park && a && nsym[s] < (uint32_t)LdsT::PRIV) pvb[nsym[s]] = (uint8_t)e[s];
+                    }
                     np[s] -= a ? (e[s] >> 8) : 0u;
                     nsym[s] += a ? 1u : 0u;
                     any |= np[s] > nl[s];
@@ -372,7 +423,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
         for (int s = 0; s < NS; s++) tsum += nsym[s];
         uint32_t tw = 0;
-        const uint32_t o = block_exclusive_scan<W, NS, OC>(tsum, L, tw);
+        const uint32_t o = block_exclusive_scan<W, NS, OC, PV>(tsum, L, tw);
         const uint32_t remaining = orig - produced;
         {
             uint32_t oo = o;
@@ -421,6 +472,12 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 ce[s] = oe[s] < cend ? oe[s] : cend;
+                if constexpr (LdsT::PRIV > 0) {
+                    if (park && nsym[s] <= (uint32_t)LdsT::PRIV) {  // whole subsequence is parked: copy this chunk's part of it
+                        if (oi[s] < ce[s]) copy_run(pv, oi[s] - o, L.outbuf, oi[s] + tshift, ce[s] - oi[s]);
+                        oi[s] = ce[s] > oi[s] ? ce[s] : oi[s];
+                    }
+                }
                 any |= oi[s] < ce[s];
             }
             while (any) {
@@ -438,7 +495,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                 if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC>(L, window32(two[s], np[s]));
+                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC, PV>(L, window32(two[s], np[s]));
                 }
                 any = false;
 #pragma unroll
@@ -492,10 +549,10 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (K >= 1024) {
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
-        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
+        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     }
 }
