@@ -48,6 +48,11 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=-1,
                     help="MiB of the stream the CPU oracle is timed on; -1 = auto (10-30 s of CPU work), 0 = off")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only exists "
+                         "to rehearse the N>1 code path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,11 +65,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = entry.load_package()  # raises if libdczhip.so is missing: no fallback
     from dcz_amd import sharding
@@ -131,7 +141,7 @@ def main():
     svc.ctx.set_profiling(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -153,7 +163,7 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
-                    traffic = json.load(f).get(args.workload, {}).get(dominant)
+                    traffic = json.load(f).get(args.workload, {}).get(dominant, {}).get("total")
             except Exception:
                 traffic = None
         value = world * per_gpu * args.steps / elapsed / 1e9
@@ -178,10 +188,8 @@ def main():
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in kern.items()},
         }
-        sample = args.cpu_sample_mib if args.cpu_sample_mib >= 0 else {"java_random": 1024, "text": 512,
-                                                                         "lowentropy": 1024}[gen]
-        if world == 1 and sample > 0:
-            line["cpu_baseline"] = cpu_baseline(np, args.workload, gen, seed, chunk, sample)
+        if world == 1 and args.cpu_sample_mib != 0:
+            line["cpu_baseline"] = cpu_baseline(np, args.workload, gen, seed, chunk, args.cpu_sample_mib)
         print(json.dumps(line), flush=True)
 
     svc.close()
@@ -192,13 +200,19 @@ def main():
 def cpu_baseline(np, workload, gen, seed, chunk, sample_mib):
     """The CPU oracle (a C port of the reference's CPU path; there is no JVM to run the reference itself)
     on a bounded sample of the same workload, with the reference's worker count max(2, min(nproc, 8))
-    (CpuCompressionService.java:42-44).  Reported baseline only."""
+    (CpuCompressionService.java:42-44).  sample_mib < 0: a 128 MiB probe sizes the sample for ~12 s of
+    CPU work (capped at 4 GiB).  Reported baseline only."""
     orc = entry.load_oracle()
-    n = (sample_mib << 20) // chunk * chunk or chunk
-    data = {"java_random": lambda: orc.java_random_bytes(seed, n), "text": lambda: orc.gen_text(seed, 0, n),
-            "lowentropy": lambda: orc.gen_lowentropy(seed, 0, n)}[gen]()
     ncpu = os.cpu_count() or 1
     threads = max(2, min(ncpu, 8))
+    make = {"java_random": lambda n: orc.java_random_bytes(seed, n), "text": lambda n: orc.gen_text(seed, 0, n),
+            "lowentropy": lambda n: orc.gen_lowentropy(seed, 0, n)}[gen]
+    if sample_mib < 0:
+        probe = (128 << 20) // chunk * chunk or chunk
+        e0, d0, _ = orc.roundtrip_blocks_mt(make(probe), chunk, threads)
+        sample_mib = int(min(4096, max(128, 12.0 / max(e0 + d0, 1e-3) * 128)))
+    n = (sample_mib << 20) // chunk * chunk or chunk
+    data = make(n)
     enc_s, dec_s, comp = orc.roundtrip_blocks_mt(data, chunk, threads)
     return {"value": round(n / (enc_s + dec_s) / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
             "sample": "%d MiB of the same stream, %d-byte chunks, %d chunk workers (host has %d cpus); "

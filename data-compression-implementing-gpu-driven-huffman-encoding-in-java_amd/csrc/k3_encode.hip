@@ -11,8 +11,9 @@
 // Design.  One WAVE owns one 32 KiB segment of a block; its first bit offset comes from K2
 // (d_seg_bitoff), so waves never wait for each other and there is no inter-workgroup traffic.
 //   * input: 16 B/lane coalesced loads (1 KiB per wave instruction), next chunk prefetched;
-//   * codebook: LDS, 256 entries of code<<6|len replicated over the 32 banks (entry s of replica r at
-//     dword s*32+r, lane l reads replica l&31) -> conflict-free ds_read_b32 for any data;
+//   * codebook: LDS, 256 entries of code<<6|len, replicated K3_COPIES times across the banks (entry s of
+//     replica r at dword s*COPIES+r, lane l reads replica l % COPIES) so that lookups of equal or different
+//     symbols by different lanes rarely collide, whatever the data;
 //   * each lane concatenates G consecutive codewords in registers (G=4 when maxlen<=16, G=2 when
 //     maxlen<=26; a wide path with 64-bit entries covers maxlen<=32), a DPP wave scan of the lane
 //     bit counts gives every lane its bit offset (no LDS, no ballot needed);
@@ -26,7 +27,16 @@
 
 namespace dcz {
 
-constexpr int K3_WAVES = 8;          // waves (= segments) per workgroup
+#ifndef DCZ_K3_WAVES
+#define DCZ_K3_WAVES 4
+#endif
+#ifndef DCZ_K3_COPIES
+#define DCZ_K3_COPIES 8
+#endif
+constexpr int K3_WAVES = DCZ_K3_WAVES;    // waves (= segments) per workgroup
+constexpr int K3_COPIES = DCZ_K3_COPIES;  // codebook replicas: 32 would be conflict-free, 8 (4 lanes per replica, a few
+                                          // 2-way conflicts) leaves room for 6 workgroups per CU and measures ~10 % faster
+constexpr int K3_CSHIFT = (K3_COPIES == 32) ? 5 : (K3_COPIES == 16) ? 4 : (K3_COPIES == 8) ? 3 : 2;
 constexpr int RING_WORDS = 1024;     // 4 KiB per wave = 32768 bits
 constexpr uint32_t RING_MASK = RING_WORDS - 1;
 
@@ -123,7 +133,7 @@ __device__ __forceinline__ void encode_chunk_packed(EncState& st, const uint32_t
         for (int k = 0; k < G; k++) {
             const int i = q * G + k;
             const uint32_t sym = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            uint32_t e = lut[(sym << 5) + col];
+            uint32_t e = lut[(sym << K3_CSHIFT) + col];
             if (i >= nb) e = 0;
             const uint32_t li = e & 63u;
             g = (g << li) | (unsigned long long)(e >> 6);
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                                                             const int32_t* __restrict__ d_status,
                                                             uint8_t* __restrict__ out) {
     // one array: [0, 8192) codebook (32 KiB), then 8 rings of 1024 dwords (32 KiB)
-    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 32 + K3_WAVES * RING_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * K3_COPIES + K3_WAVES * RING_WORDS];
     const uint32_t b = blockIdx.x / groups_per_block;
     const uint32_t grp = blockIdx.x % groups_per_block;
     const int tid = (int)threadIdx.x;
@@ -197,8 +207,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     uint32_t* lut = lds;
     unsigned long long* lut64 = reinterpret_cast<unsigned long long*>(lds);
     if (!wide) {
-        for (int i = tid; i < 256 * 32; i += K3_WAVES * 64) {
-            const int s = i >> 5;
+        for (int i = tid; i < 256 * K3_COPIES; i += K3_WAVES * 64) {
+            const int s = i >> K3_CSHIFT;
             lut[i] = (d_code[(uint64_t)b * 256u + s] << 6) | (uint32_t)d_len[(uint64_t)b * 256u + s];
         }
     } else {
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
             lut64[s] = ((unsigned long long)d_code[(uint64_t)b * 256u + s] << 8) |
                        (unsigned long long)d_len[(uint64_t)b * 256u + s];
     }
-    uint32_t* ring = lds + 256 * 32 + w * RING_WORDS;
+    uint32_t* ring = lds + 256 * K3_COPIES + w * RING_WORDS;
     {
         uint4* r4 = reinterpret_cast<uint4*>(ring);
 #pragma unroll
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     st.gbase = (blk_out - a) + (origin >> 3);
     st.rpos = (uint32_t)(v0 - origin);
     st.rflush = (st.rpos + 7u) >> 3;  // first byte whose first bit is ours
-    const uint32_t col = (uint32_t)lane & 31u;
+    const uint32_t col = (uint32_t)lane & (uint32_t)(K3_COPIES - 1);
     const bool fast = (((uintptr_t)src) & 15u) == 0u;
     // If the first owned byte is exactly the start of ring chunk 1, chunk 0 only ever holds the few leading
     // bits that belong to the previous segment's last byte: it is never flushed, so it must be cleared by

@@ -39,6 +39,8 @@ def gather_chunk_sizes(local_sizes, num_chunks, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     per = chunks_per_rank(num_chunks, world)
     dev = local_sizes.device
+    if world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        dev = torch.device("cpu")  # rehearsal transport: gloo moves host tensors
     padded = torch.zeros(per, dtype=torch.int64, device=dev)
     padded[: local_sizes.numel()] = local_sizes.to(torch.int64)
     if world > 1:
