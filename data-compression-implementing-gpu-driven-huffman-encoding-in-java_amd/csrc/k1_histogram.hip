@@ -5,21 +5,32 @@
 // (one work-item per 64 KiB tile; 256 work-items for a 16 MiB chunk).
 //
 // Design (HBM-bound, integer): one WAVE owns one segment and streams it with 16 B/lane coalesced loads.
-// Counting uses LDS atomics into a wave-private histogram that is replicated over the 32 LDS banks:
-//   dword[(bin & 127) * 32 + (lane & 31)], low half = bin < 128, high half = bin >= 128.
-// Lane l only ever touches bank l & 31, so every ds_add_u32 is conflict-free for ANY data
-// distribution (all-zero input included); lanes l and l+32 are serviced in different LDS cycles.
-// A (lane pair, bin) count is at most 1024 per segment, a bin total at most 32768: u16 halves
-// never carry into each other, and the 32 replicas can be summed as packed dwords.
+// Counting uses LDS atomics into a wave-private histogram replicated K1_COPIES times across the banks:
+//   dword[(bin & 127) * COPIES + (lane % COPIES)], low half = bin < 128, high half = bin >= 128.
+// With 32 replicas every ds_add_u32 is conflict-free for ANY data; with 16 (the default) lanes l and l+16 share
+// a replica, so the worst case -- every byte equal, BASELINE config 5 -- is a 2-way same-address serialisation,
+// while the halved LDS footprint doubles the resident waves.  Measured on MI355X (8 GiB): 32 replicas 2.12 ms
+// random / 2.16 ms 99%-zeros; 16 replicas 1.55 / 1.80 ms; 8 replicas 1.64 / 3.40 ms.
+// A (lane group, bin) count is at most a few thousand per segment, a bin total at most 32768: u16 halves never
+// carry into each other, and the replicas can be summed as packed dwords.
 // No global atomics, no inter-workgroup traffic: K2 sums the segment rows of its block.
 #include "dcz_internal.h"
 
 namespace dcz {
 
-constexpr int K1_WAVES = 4;  // 4 x 16 KiB of LDS per workgroup -> 2 workgroups (8 waves) per CU
+#ifndef DCZ_K1_COPIES
+#define DCZ_K1_COPIES 16
+#endif
+#ifndef DCZ_K1_WAVES
+#define DCZ_K1_WAVES 4
+#endif
+constexpr int K1_WAVES = DCZ_K1_WAVES;    // waves (= segments) per workgroup
+constexpr int K1_COPIES = DCZ_K1_COPIES;  // histogram replicas per wave: 32 = one per bank (conflict-free for any data)
+constexpr int K1_CSHIFT = (K1_COPIES == 32) ? 5 : (K1_COPIES == 16) ? 4 : 3;
+constexpr int K1_DW = 128 * K1_COPIES;    // dwords per wave-private histogram
 
 __device__ __forceinline__ void hist_add(uint32_t* h, uint32_t col, uint32_t byte) {
-    const uint32_t idx = ((byte & 127u) << 5) + col;
+    const uint32_t idx = ((byte & 127u) << K1_CSHIFT) + col;
     const uint32_t val = (byte >> 7) * 0xFFFFu + 1u;  // 1 or 0x10000
     __hip_atomic_fetch_add(&h[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -41,19 +52,19 @@ __device__ __forceinline__ void hist_add_vec(uint32_t* h, uint32_t col, const ui
 __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __restrict__ in, size_t n,
                                                                size_t block_bytes, uint32_t spb, uint64_t nseg,
                                                                uint16_t* __restrict__ seg_hist) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[K1_WAVES][128 * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[K1_WAVES][K1_DW];
     const int w = (int)(threadIdx.x >> 6);
     const int lane = lane_id();
     const uint64_t seg = (uint64_t)blockIdx.x * K1_WAVES + (uint64_t)w;
     if (seg >= nseg) return;  // wave-uniform; this kernel has no workgroup barrier
     uint32_t* h = lds[w];
-    const uint32_t col = (uint32_t)lane & 31u;
+    const uint32_t col = (uint32_t)lane & (uint32_t)(K1_COPIES - 1);
 
     {
         uint4* h4 = reinterpret_cast<uint4*>(h);
         const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; i++) h4[i * 64 + lane] = z;
+        for (int i = 0; i < K1_DW / 4 / 64; i++) h4[i * 64 + lane] = z;
     }
     wave_lds_fence();
 
@@ -100,15 +111,15 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
     }
     wave_lds_fence();
 
-    // Sum the 32 replicas. Lane l owns rows l and l+64 (bins l, l+128 and l+64, l+192).  The 16-B
-    // chunk order is rotated by lane>>1 so that every ds_read_b128 lane group touches 16 distinct
-    // 4-bank slots (row parity x chunk) -> conflict-free.
+    // Sum the replicas. Lane l owns rows l and l+64 (bins l, l+128 and l+64, l+192).  The 16-byte chunk order is
+    // rotated by lane so that the lanes of a ds_read_b128 group spread over the banks.
     uint32_t acc0 = 0, acc1 = 0;
-    const uint4* r0 = reinterpret_cast<const uint4*>(h + (uint32_t)lane * 32u);
-    const uint4* r1 = reinterpret_cast<const uint4*>(h + ((uint32_t)lane + 64u) * 32u);
+    const uint4* r0 = reinterpret_cast<const uint4*>(h + (uint32_t)lane * (uint32_t)K1_COPIES);
+    const uint4* r1 = reinterpret_cast<const uint4*>(h + ((uint32_t)lane + 64u) * (uint32_t)K1_COPIES);
+    constexpr int NQ = K1_COPIES / 4;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int q = (t + (lane >> 1)) & 7;
+    for (int t = 0; t < NQ; t++) {
+        const int q = (t + (lane >> 1)) & (NQ - 1);
         const uint4 a = r0[q];
         const uint4 c = r1[q];
         acc0 += a.x + a.y + a.z + a.w;

@@ -66,7 +66,7 @@ constexpr int TB = DCZ_K4_TB;
 
 template <int W, int NS, int OC, int PV>
 struct DecLds {
-    static_assert(W >= 256 && W % 64 == 0, "the table build assumes at least 256 threads");
+    static_assert(W >= 64 && W % 64 == 0, "whole waves only");
     static constexpr int NSUB = W * NS;
     static constexpr int STRIPE = SUB_DW * NS;   // payload dwords per thread
     static constexpr int STRIDE = STRIPE + 3;    // + 2 look-ahead dwords + 1 pad (odd => conflict-free)
@@ -214,12 +214,11 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         L.err_idx = 0xFFFFFFFFu;
     }
     __syncthreads();
-    uint32_t mylen = 0;
-    if (tid < 256) {
-        mylen = d_len[(uint64_t)b * 256u + tid];
-        L.len8[tid] = (uint8_t)mylen;
-        if (mylen > 32) L.bad_table = 1;
-        else if (mylen > 0) atomicAdd(&L.cnt[mylen], 1u);
+    for (int sy = tid; sy < 256; sy += W) {
+        const uint32_t l = d_len[(uint64_t)b * 256u + sy];
+        L.len8[sy] = (uint8_t)l;
+        if (l > 32) L.bad_table = 1;
+        else if (l > 0) atomicAdd(&L.cnt[l], 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -246,10 +245,13 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         }
         return;
     }
-    if (tid < 256 && mylen > 0) {
-        uint32_t rank = 0;
-        for (int s = 0; s < tid; s++) rank += (L.len8[s] == mylen) ? 1u : 0u;
-        L.symtab[L.offs[mylen] + rank] = (uint8_t)tid;
+    for (int sy = tid; sy < 256; sy += W) {
+        const uint32_t l = L.len8[sy];
+        if (l > 0) {
+            uint32_t rank = 0;
+            for (int t = 0; t < sy; t++) rank += (L.len8[t] == l) ? 1u : 0u;
+            L.symtab[L.offs[l] + rank] = (uint8_t)sy;
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < (1 << TB); idx += W) {
@@ -549,6 +551,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (K >= 1024) {
+        static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
         hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
