@@ -201,7 +201,7 @@ def cpu_baseline(np, workload, gen, seed, chunk, sample_mib):
     """The CPU oracle (a C port of the reference's CPU path; there is no JVM to run the reference itself)
     on a bounded sample of the same workload, with the reference's worker count max(2, min(nproc, 8))
     (CpuCompressionService.java:42-44).  sample_mib < 0: a 128 MiB probe sizes the sample for ~12 s of
-    CPU work (capped at 4 GiB).  Reported baseline only."""
+    CPU work (capped at 8 GiB).  Reported baseline only."""
     orc = entry.load_oracle()
     ncpu = os.cpu_count() or 1
     threads = max(2, min(ncpu, 8))
@@ -210,7 +210,7 @@ def cpu_baseline(np, workload, gen, seed, chunk, sample_mib):
     if sample_mib < 0:
         probe = (128 << 20) // chunk * chunk or chunk
         e0, d0, _ = orc.roundtrip_blocks_mt(make(probe), chunk, threads)
-        sample_mib = int(min(4096, max(128, 12.0 / max(e0 + d0, 1e-3) * 128)))
+        sample_mib = int(min(8192, max(128, 12.0 / max(e0 + d0, 1e-3) * 128)))
     n = (sample_mib << 20) // chunk * chunk or chunk
     data = make(n)
     enc_s, dec_s, comp = orc.roundtrip_blocks_mt(data, chunk, threads)

@@ -29,6 +29,8 @@
 // first-code/count search, which for a prefix code returns exactly what the reference's
 // 10-bit-table-then-HashMap path returns.  Bits past the end of the payload read as zero
 // (TableBasedHuffmanDecoder.java:204-208); a missing code is "Huffman decode error at position i" (:109-111).
+#include <cstdlib>
+
 #include "dcz_internal.h"
 
 namespace dcz {
@@ -58,7 +60,7 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4S_PRIV 64  // few-blocks kernel: one workgroup per CU anyway, so LDS is free and parking pays
 #endif
 #ifndef DCZ_K4S_OC
-#define DCZ_K4S_OC 16384 // few-blocks kernel (one 1024-thread workgroup per block)
+#define DCZ_K4S_OC 32768 // few-blocks kernel (one 1024-thread workgroup per block owns the CU: use its LDS)
 #endif
 #ifndef DCZ_K4S_NS
 #define DCZ_K4S_NS 1
@@ -80,6 +82,7 @@ struct DecLds {
     uint32_t priv[W * PRIV_DW + 4];
     uint16_t table[1 << TB];
     uint16_t exits[NSUB];
+    unsigned long long lim[40];  // lim[l] = (first[l] + cnt[l]) << (32 - l): exclusive left-aligned upper bound of length l
     uint32_t first[34];
     uint32_t cnt[34];
     uint32_t offs[34];
@@ -109,14 +112,21 @@ __device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t np
     return (uint32_t)(two >> ((npos & 31u) + 1u));
 }
 
-// Long-code / invalid-code path: canonical search over lengths TB+1..maxlen on the next 32 bits.
+// Codes longer than TB bits, and invalid patterns.  Canonical code ranges are contiguous and ascending in the
+// length, and everything below the TB+1 range was already answered by the table, so the length of window w is
+// the first l > TB with w < lim[l] (64-bit, left-aligned); four independent LDS reads per step.  No match = no
+// codeword (the reference's "decode error at position i").
 template <int W, int NS, int OC, int PV>
-__device__ __noinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV>& L, uint32_t win32) {
+__device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV>& L, uint32_t win32) {
     const uint32_t maxlen = L.maxlen;
-    for (uint32_t l = TB + 1; l <= maxlen; l++) {
-        const uint32_t c = win32 >> (32u - l);
-        const uint32_t f = L.first[l];
-        if (c >= f && c - f < L.cnt[l]) return (l << 8) | (uint32_t)L.symtab[L.offs[l] + (c - f)];
+    const unsigned long long w = win32;
+    for (uint32_t l = TB + 1; l <= maxlen; l += 4) {
+        const unsigned long long a = L.lim[l], b = L.lim[l + 1], c = L.lim[l + 2], d = L.lim[l + 3];
+        const uint32_t k = (w < a) ? 0u : (w < b) ? 1u : (w < c) ? 2u : (w < d) ? 3u : 4u;
+        if (k < 4u) {
+            const uint32_t ll = l + k;  // <= maxlen: lim[] is flat beyond maxlen, so a later length never wins
+            return (ll << 8) | (uint32_t)L.symtab[L.offs[ll] + ((win32 >> (32u - ll)) - L.first[ll])];
+        }
     }
     return 0;
 }
@@ -233,7 +243,10 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             o += L.cnt[l];
             if (L.cnt[l]) mx = (uint32_t)l;
             kraft += (unsigned long long)L.cnt[l] << (32 - l);
+            L.lim[l] = (unsigned long long)(c + L.cnt[l]) << (32 - l);
         }
+        L.lim[0] = 0;
+        for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
         if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
     }
@@ -281,10 +294,11 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     const unsigned long long vhi = (unsigned long long)skew + csize;  // one past the last valid virtual byte
     (void)comp_bytes;
 
-    // Park symbols only when a 32-byte subsequence is expected to hold at most ~7/8 of the private capacity
-    // (average code length from the block's own sizes); otherwise most subsequences would overflow and be
-    // decoded twice anyway.
-    const bool park = LdsT::PRIV > 0 && (unsigned long long)orig * 32ull * 8ull <= (unsigned long long)csize * 7ull * (unsigned long long)LdsT::PRIV;
+    // Park symbols only when a 32-byte subsequence is expected to hold at most 3/4 of the private capacity
+    // (expected symbols = 32 * orig / csize from the block's own sizes); otherwise too many subsequences
+    // overflow and are decoded twice anyway.
+    const bool park = LdsT::PRIV > 0 &&
+                      (unsigned long long)orig * 128ull <= (unsigned long long)csize * 3ull * (unsigned long long)LdsT::PRIV;
     unsigned long long ventry = 8ull * skew;  // virtual bit of the next codeword boundary
     uint32_t produced = 0;                    // symbols decoded so far
     uint32_t gpos = 0;                        // block-relative output offset of tile byte 0 (multiple of 16)
@@ -349,6 +363,23 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         }
         if (tid == 0) g[0] = g0;
         const uint32_t q0 = (uint32_t)tid * NS;  // first subsequence of this thread
+        // Subsequences that START past the payload hold nothing but zero padding: a periodic stream of the shortest
+        // code that never self-synchronises when its length does not divide 256 (measured: W sync rounds in the last
+        // window of every text block).  They take no part in phase A; the symbols the reference would read from
+        // that padding are filled in after the window (see "exhausted").
+        const unsigned long long wbase_bits = wchunk0 << 7;
+        const unsigned long long pay_end_bits = vhi << 3;
+        const bool exhausted = wbase_bits + (unsigned long long)LdsT::NSUB * SUB_BITS >= pay_end_bits;
+        bool beyond[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) beyond[s] = false;
+        if (exhausted) {  // workgroup-uniform: only the last window(s) of a block
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                beyond[s] = wbase_bits + (unsigned long long)(q0 + s) * SUB_BITS >= pay_end_bits;
+                if (beyond[s]) need[s] = false;
+            }
+        }
         while (true) {
             // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
             // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are
@@ -413,7 +444,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             for (int s = 0; s < NS; s++) {
                 const uint32_t q = q0 + s;
                 const uint32_t ng = (q == 0) ? g0 : (uint32_t)L.exits[q - 1];
-                need[s] = (ng != g[s]);
+                need[s] = (ng != g[s]) && !beyond[s];
                 g[s] = ng;
                 anyneed |= need[s];
             }
@@ -535,6 +566,19 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         }
         produced += lim;
         ventry = next_ventry;
+        if (exhausted && produced < orig) {
+            // The payload is used up but the chunk wants more symbols: the reference keeps reading zero bits
+            // (TableBasedHuffmanDecoder.java:204-208), i.e. the all-zero codeword = first canonical symbol, forever.
+            if ((uint32_t)tid < ocarry) oblk[gpos + tid] = ob[opad((uint32_t)tid)];  // unflushed tail (gpos + ocarry == produced)
+            if (L.maxlen == 0) {  // empty table: no codeword at all
+                status = DCZ_E_BADSTREAM;
+                errpos = (long long)produced;
+            } else {
+                const uint8_t z = L.symtab[0];
+                for (uint32_t i = produced + (uint32_t)tid; i < orig; i += W) oblk[i] = z;
+            }
+            break;
+        }
         __syncthreads();
     }
 
@@ -550,7 +594,12 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     if (K == 0) return;
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
-    if (K >= 1024) {
+    // Below this many blocks one 1024-thread workgroup per block keeps more waves resident than 256-thread ones.
+    static const uint32_t few_below = [] {
+        const char* e = getenv("DCZ_K4_FEW_BLOCKS_BELOW");  // tuning knob
+        return e ? (uint32_t)atoi(e) : 1024u;
+    }();
+    if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
         hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep);
