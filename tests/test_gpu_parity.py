@@ -429,3 +429,37 @@ def test_file_service_round_trip_container(svc, orc, pkg, tmp_path):
     assert (tmp_path / "empty.dcz").stat().st_size == 85
     svc.decompress(tmp_path / "empty.dcz", back)
     assert back.read_bytes() == b""
+
+
+def test_zero_padding_semantics_match_reference(pkg, svc, orc):
+    """Bits past the end of the payload read as zero (TableBasedHuffmanDecoder.java:204-208): a chunk that asks
+    for more symbols than its payload holds keeps decoding the all-zero codeword.  The HIP decoder keeps that
+    padding out of its sync fixed point and fills analytically; both must agree with the oracle."""
+    data = orc.gen_text(9, 0, 70000)
+    pay, lens = orc.encode_block(data)
+    for cut, want in [(pay.size, data.size + 5000), (pay.size // 3, data.size), (0, 4000), (1, 300), (17, 70000)]:
+        comp = pay[:cut] if cut else np.zeros(0, np.uint8)
+        assert (svc.decode_chunk(comp, lens, want) == orc.decode_block(comp, lens, want)).all(), (cut, want)
+    # shortest code of length 3 (256 % 3 != 0): padding is a periodic stream that never self-synchronises
+    l3 = np.zeros(256, np.int32)
+    l3[[10, 20, 30, 40, 50, 60, 70, 80]] = 3
+    codes, _ = orc.canonical_codes(l3)
+    rng = np.random.default_rng(5)
+    msg = rng.choice([10, 20, 30, 40, 50, 60, 70, 80], size=50000).astype(np.uint8)
+    p3, _ = orc.encode_block(msg, l3, codes)
+    assert (svc.decode_chunk(p3, l3, 120000) == orc.decode_block(p3, l3, 120000)).all()
+
+
+@pytest.mark.parametrize("period_len", [3, 5, 7])
+def test_periodic_runs_inside_a_block(svc, orc, period_len):
+    """A long run of one symbol whose code length does not divide the 256-bit subsequence never self-synchronises
+    from a wrong phase; the decoder must still converge (slowly) to the exact parse."""
+    rng = np.random.default_rng(period_len)
+    nsym = 1 << period_len  # complete fixed-length code of `period_len` bits
+    alphabet = rng.choice(256, size=nsym, replace=False).astype(np.uint8)
+    body = np.full(300000, alphabet[0], np.uint8)          # the run: a periodic bit pattern
+    noise = rng.choice(alphabet, size=40000).astype(np.uint8)
+    data = np.concatenate([noise, body, noise, alphabet])  # every symbol present -> all lengths equal
+    lens, _ = orc.build_canonical_codes(orc.histogram(data))
+    assert_parity(svc, orc, data, data.size)
+    assert_parity(svc, orc, data[: (data.size // 5) * 5], data.size // 5)

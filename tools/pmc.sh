@@ -7,4 +7,4 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --cpu-sample-mib 0 --no-verify > /dev/null 2> $R/gpurun_out/pmc_${TAG}_$i.err || echo "pass $i failed"
 done
-cd $R && python3 scratch/pmcsum.py gpurun_out/pmc_${TAG}_*/
+cd $R && python3 tools/pmcsum.py gpurun_out/pmc_${TAG}_*/
