@@ -24,12 +24,12 @@ namespace dcz {
 
 constexpr int K2_T = 64;  // threads per block-workgroup (one wave)
 
+// 3.6 KiB per block-wave: all 32 wave slots of a CU can hold a block (the block histogram lives in registers,
+// lane t owns symbols 4t..4t+3, and is only staged inside the heap array for the serial build).
 struct CodeLds {
     __attribute__((aligned(16))) unsigned long long heap[260];  // slot i+1 holds PriorityQueue.queue[i]
-    unsigned long long hist[256];
     uint32_t cnt[34];
     uint32_t first[34];
-    uint32_t code[256];
     uint16_t parent[512];
     uint8_t len[256];
     int nsym;
@@ -78,13 +78,17 @@ __device__ __forceinline__ unsigned long long heap_poll(unsigned long long* q, i
     return result;
 }
 
-// Code lengths for hist[] in LDS (L.hist) -> L.len, L.maxlen, L.nsym.  All K2_T threads call this.
-__device__ void build_lengths(CodeLds& L) {
+// Code lengths for the block histogram hf[i] = count of symbol 4*tid+i -> L.len, L.maxlen, L.nsym.
+__device__ void build_lengths(CodeLds& L, const unsigned long long (&hf)[4]) {
     const int tid = (int)threadIdx.x;
     int mine = 0;
-    for (int s = tid; s < 256; s += K2_T) {
-        mine += (L.hist[s] > 0) ? 1 : 0;
-        L.len[s] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        mine += (hf[i] > 0) ? 1 : 0;
+        L.len[4 * tid + i] = 0;
+        // Stage the weights for the serial build at heap slot s+2: offering symbol s reads slot s+2 and writes only
+        // slots <= s+1 (the heap holds at most s entries before it), so the staging is consumed before it is reused.
+        L.heap[4 * tid + i + 2] = hf[i];
     }
     const int nsym = (int)wave_reduce_add_u32((uint32_t)mine);
     if (tid == 0) {
@@ -94,9 +98,10 @@ __device__ void build_lengths(CodeLds& L) {
     __syncthreads();
     if (nsym == 0) return;  // core/CanonicalHuffman.java:30-32
     if (nsym == 1) {        // core/CanonicalHuffman.java:35-45: the single symbol gets length 1, code 0
-        for (int s = tid; s < 256; s += K2_T)
-            if (L.hist[s] > 0) {
-                L.len[s] = 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (hf[i] > 0) {
+                L.len[4 * tid + i] = 1;
                 L.maxlen = 1;
             }
         __syncthreads();
@@ -105,7 +110,7 @@ __device__ void build_lengths(CodeLds& L) {
     if (tid == 0) {
         int size = 0;
         for (int s = 0; s < 256; s++) {  // core/CanonicalHuffman.java:59-63: leaves in symbol order
-            const unsigned long long w = L.hist[s];
+            const unsigned long long w = L.heap[s + 2];
             if (w > 0) heap_offer(L.heap, size, (w << 18) | ((unsigned long long)(s + 1) << 9) | (unsigned long long)s);
         }
         int nn = 256;
@@ -122,24 +127,25 @@ __device__ void build_lengths(CodeLds& L) {
     }
     __syncthreads();
     // core/CanonicalHuffman.java:85-92 extractLengths: depth of each leaf
-    for (int s = tid; s < 256; s += K2_T) {
-        if (L.hist[s] > 0) {
-            int d = 0, x = s;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (hf[i] > 0) {
+            int d = 0, x = 4 * tid + i;
             while (true) {
                 const int p = L.parent[x];
                 if (p == 0xFFFF) break;
                 x = p;
                 d++;
             }
-            L.len[s] = (uint8_t)(d > 255 ? 255 : d);
+            L.len[4 * tid + i] = (uint8_t)(d > 255 ? 255 : d);
             atomicMax(&L.maxlen, d);
         }
     }
     __syncthreads();
 }
 
-// core/CanonicalHuffman.java:99-132 generateCanonicalCodes, from L.len (all <= 32) -> L.code.
-__device__ void canonical_codes(CodeLds& L) {
+// core/CanonicalHuffman.java:99-132 generateCanonicalCodes, from L.len (all <= 32) -> out[256] (global memory).
+__device__ void canonical_codes(CodeLds& L, uint32_t* __restrict__ out, bool zero_all) {
     const int tid = (int)threadIdx.x;
     if (tid < 34) L.cnt[tid] = 0;
     __syncthreads();
@@ -174,7 +180,7 @@ __device__ void canonical_codes(CodeLds& L) {
             __syncthreads();
             todo &= ~same;
         }
-        L.code[sym] = code;
+        out[sym] = zero_all ? 0u : code;
     }
     __syncthreads();
 }
@@ -200,37 +206,39 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
     const uint16_t* rows = seg_hist ? seg_hist + (uint64_t)b * spb * 256u : nullptr;
 
     // block histogram = sum of its segment rows (lane t owns bins 4t..4t+3: one 8-byte load per row)
+    unsigned long long hf[4] = {0, 0, 0, 0};
     if (seg_hist) {
-        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         for (uint32_t j = 0; j < nsb; j++) {
             const uint2 v = *reinterpret_cast<const uint2*>(rows + (uint64_t)j * 256u + 4u * (uint32_t)tid);
-            f0 += v.x & 0xFFFFu;
-            f1 += v.x >> 16;
-            f2 += v.y & 0xFFFFu;
-            f3 += v.y >> 16;
+            hf[0] += v.x & 0xFFFFu;
+            hf[1] += v.x >> 16;
+            hf[2] += v.y & 0xFFFFu;
+            hf[3] += v.y >> 16;
         }
-        L.hist[4 * tid + 0] = f0;
-        L.hist[4 * tid + 1] = f1;
-        L.hist[4 * tid + 2] = f2;
-        L.hist[4 * tid + 3] = f3;
     } else {
-        for (int s = tid; s < 256; s += K2_T) L.hist[s] = (unsigned long long)hist_in[(uint64_t)b * 256u + s];
+#pragma unroll
+        for (int i = 0; i < 4; i++) hf[i] = (unsigned long long)hist_in[(uint64_t)b * 256u + 4 * tid + i];
     }
-    __syncthreads();
 
-    build_lengths(L);
+    build_lengths(L, hf);
     const int maxlen = L.maxlen;
     const bool too_long = maxlen > 32;  // core/CanonicalHuffman.java:102-106 would throw
-    if (too_long)
-        for (int s = tid; s < 256; s += K2_T) L.len[s] = 0;
+    if (too_long) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) L.len[4 * tid + i] = 0;
+    }
     __syncthreads();
-    canonical_codes(L);
+    canonical_codes(L, d_code + (uint64_t)b * 256u, false);
     unsigned long long bits = 0;
-    for (int s = tid; s < 256; s += K2_T) {
-        const uint32_t l = L.len[s];
-        d_len[(uint64_t)b * 256u + s] = (uint8_t)l;
-        d_code[(uint64_t)b * 256u + s] = L.code[s];
-        bits += L.hist[s] * (unsigned long long)l;
+    {
+        uint32_t l4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t l = L.len[4 * tid + i];
+            l4 |= l << (8 * i);
+            bits += hf[i] * (unsigned long long)l;
+        }
+        reinterpret_cast<uint32_t*>(d_len + (uint64_t)b * 256u)[tid] = l4;
     }
     bits = wave_reduce_add_u64(bits);
     if (tid == 0) {
@@ -282,8 +290,7 @@ __global__ __launch_bounds__(K2_T) void k2_codes_from_lengths(const int32_t* __r
     const bool bad = __builtin_amdgcn_ballot_w64(mybad) != 0ull;
     for (int s = tid; s < 256; s += K2_T) L.len[s] = bad ? 0 : (uint8_t)len32[s];
     __syncthreads();
-    canonical_codes(L);
-    for (int s = tid; s < 256; s += K2_T) d_code[s] = bad ? 0u : L.code[s];
+    canonical_codes(L, d_code, bad);
     if (tid == 0) d_status[0] = bad ? DCZ_E_BADTABLE : DCZ_OK;
 }
 
