@@ -15,6 +15,10 @@ using namespace dcz;
 struct dcz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;       // second stream: code build of one half overlaps K1/K3 of the other half
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t* carry = nullptr;       // device u64: payload bytes of the first half
+    bool pipeline = true;
     std::string err;
     // batch workspace
     uint16_t* seg_hist = nullptr;
@@ -225,9 +229,14 @@ int dcz_ctx_create(int device, dcz_ctx** out) {
     dcz_ctx* c = new dcz_ctx();
     c->device = device;
     DeviceGuard g(device);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->st_meta), 8192) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->st_meta), 8192) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->carry), 64) == hipSuccess;
+    for (auto& e : c->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (const char* np = std::getenv("DCZ_NO_PIPELINE")) c->pipeline = !(np[0] && np[0] != '0');
+    if (!ok) {
+        dcz_ctx_destroy(c);
         return DCZ_E_HIP;
     }
     *out = c;
@@ -237,7 +246,8 @@ int dcz_ctx_create(int device, dcz_ctx** out) {
 void dcz_ctx_destroy(dcz_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     for (auto& ev : c->pending) {
         (void)hipEventDestroy(ev.a);
         (void)hipEventDestroy(ev.b);
@@ -250,7 +260,11 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     (void)hipFree(c->st_in);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
-    (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->carry);
+    for (auto e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -296,23 +310,67 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
     r = reserve(c, g);
     if (r != DCZ_OK) return r;
     const uint8_t* in = static_cast<const uint8_t*>(d_in);
-    {
-        KernelTimer t(c, s, DCZ_K_HISTOGRAM);
-        launch_histogram(in, n, block_bytes, g.spb, g.nseg, c->seg_hist, s);
-    }
-    {
-        KernelTimer t(c, s, DCZ_K_CODEBUILD);
-        launch_codebuild(c->seg_hist, nullptr, n, block_bytes, g.spb, g.K, d_len, c->code, c->maxlen, d_comp_size,
-                         c->seg_bitoff, d_status, s);
-    }
-    {
-        KernelTimer t(c, s, DCZ_K_OFFSETS);
-        launch_offsets(d_comp_size, g.K, d_comp_off, d_total, out_cap, d_status, s);
-    }
-    {
-        KernelTimer t(c, s, DCZ_K_ENCODE);
-        launch_encode(in, n, block_bytes, g.spb, g.K, d_len, c->code, c->maxlen, d_comp_off, c->seg_bitoff, d_status,
-                      static_cast<uint8_t*>(d_out), s);
+    uint8_t* out = static_cast<uint8_t*>(d_out);
+    // One block range [k0, k0+kn): K1 -> K2 -> offsets -> K3.  With many blocks the call is cut in two halves and the
+    // latency-bound code build (K2) of one half runs on a second stream while the bandwidth-bound K1/K3 of the other
+    // half keep the memory system busy; events order everything, nothing synchronises with the host.
+    auto range = [&](uint32_t k0, uint32_t kn, size_t* off_b, size_t* len_b, uint64_t* seg0) {
+        *off_b = (size_t)k0 * block_bytes;
+        const size_t end = ((size_t)(k0 + kn) * block_bytes < n) ? (size_t)(k0 + kn) * block_bytes : n;
+        *len_b = end - *off_b;
+        *seg0 = (uint64_t)k0 * g.spb;
+    };
+    auto k1 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
+        size_t ob, lb;
+        uint64_t s0;
+        range(k0, kn, &ob, &lb, &s0);
+        KernelTimer t(c, st, DCZ_K_HISTOGRAM);
+        launch_histogram(in + ob, lb, block_bytes, g.spb, (uint64_t)kn * g.spb, c->seg_hist + s0 * 256u, st);
+    };
+    auto k2 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
+        size_t ob, lb;
+        uint64_t s0;
+        range(k0, kn, &ob, &lb, &s0);
+        KernelTimer t(c, st, DCZ_K_CODEBUILD);
+        launch_codebuild(c->seg_hist + s0 * 256u, nullptr, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u,
+                         c->code + (size_t)k0 * 256u, c->maxlen + k0, d_comp_size + k0, c->seg_bitoff + s0,
+                         d_status + k0, st);
+    };
+    auto k3 = [&](uint32_t k0, uint32_t kn, const uint64_t* carry_in, uint64_t* total_out, hipStream_t st) {
+        size_t ob, lb;
+        uint64_t s0;
+        range(k0, kn, &ob, &lb, &s0);
+        {
+            KernelTimer t(c, st, DCZ_K_OFFSETS);
+            launch_offsets(d_comp_size + k0, kn, d_comp_off + k0, total_out, carry_in, out_cap, d_status + k0, st);
+        }
+        KernelTimer t(c, st, DCZ_K_ENCODE);
+        launch_encode(in + ob, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u, c->code + (size_t)k0 * 256u,
+                      c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st);
+    };
+    if (c->pipeline && g.K >= 2048) {
+        const uint32_t ka = g.K / 2, kb = g.K - ka;
+        hipStream_t a = c->aux;
+        HIPCHK(c, hipEventRecord(c->ev[0], s));  // the aux stream must not run ahead of the caller's earlier work
+        HIPCHK(c, hipStreamWaitEvent(a, c->ev[0], 0));
+        k1(0, ka, s);
+        HIPCHK(c, hipEventRecord(c->ev[1], s));
+        HIPCHK(c, hipStreamWaitEvent(a, c->ev[1], 0));
+        k2(0, ka, a);  // overlaps K1 of the second half
+        HIPCHK(c, hipEventRecord(c->ev[2], a));
+        k1(ka, kb, s);
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, hipStreamWaitEvent(a, c->ev[3], 0));
+        k2(ka, kb, a);  // overlaps K3 of the first half
+        HIPCHK(c, hipEventRecord(c->ev[4], a));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev[2], 0));
+        k3(0, ka, nullptr, c->carry, s);
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev[4], 0));
+        k3(ka, kb, c->carry, d_total ? d_total : c->carry + 1, s);
+    } else {
+        k1(0, g.K, s);
+        k2(0, g.K, s);
+        k3(0, g.K, nullptr, d_total, s);
     }
     return launch_check(c);
 }

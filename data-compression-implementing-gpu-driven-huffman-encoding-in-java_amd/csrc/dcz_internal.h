@@ -26,8 +26,9 @@ void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t
 // Canonical codes from stored lengths (CH.generateCanonicalCodesFromLengths), one block per workgroup.
 void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s);
 // Exclusive scan of comp_size -> comp_off, total, capacity check.
-void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total, size_t out_cap,
-                    int32_t* d_status, hipStream_t s);
+// d_carry_in (nullable): payload bytes that precede this block range; d_total receives carry + sum.
+void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total,
+                    const uint64_t* d_carry_in, size_t out_cap, int32_t* d_status, hipStream_t s);
 
 // K3: encode.
 void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,

@@ -298,11 +298,12 @@ __global__ __launch_bounds__(K2_T) void k2_codes_from_lengths(const int32_t* __r
 __global__ __launch_bounds__(1024) void k2_offsets(const uint32_t* __restrict__ comp_size, uint32_t K,
                                                    unsigned long long* __restrict__ comp_off,
                                                    unsigned long long* __restrict__ d_total,
+                                                   const unsigned long long* __restrict__ carry_in,
                                                    unsigned long long out_cap, int32_t* __restrict__ d_status) {
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry_s;
     const int tid = (int)threadIdx.x;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) carry_s = carry_in ? *carry_in : 0ull;  // payload bytes of the blocks before this range
     __syncthreads();
     for (uint32_t c0 = 0; c0 < K; c0 += 1024) {
         const uint32_t k = c0 + (uint32_t)tid;
@@ -345,11 +346,12 @@ void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t
     hipLaunchKernelGGL(k2_codes_from_lengths, dim3(1), dim3(K2_T), 0, s, d_len32, d_code, d_status);
 }
 
-void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total, size_t out_cap,
-                    int32_t* d_status, hipStream_t s) {
+void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_off, uint64_t* d_total,
+                    const uint64_t* d_carry_in, size_t out_cap, int32_t* d_status, hipStream_t s) {
     hipLaunchKernelGGL(k2_offsets, dim3(1), dim3(1024), 0, s, d_comp_size, K,
                        reinterpret_cast<unsigned long long*>(d_comp_off),
-                       reinterpret_cast<unsigned long long*>(d_total), (unsigned long long)out_cap, d_status);
+                       reinterpret_cast<unsigned long long*>(d_total),
+                       reinterpret_cast<const unsigned long long*>(d_carry_in), (unsigned long long)out_cap, d_status);
 }
 
 }  // namespace dcz
