@@ -20,8 +20,29 @@ def _stale():
     return False
 
 
+HOST_SOURCES = [os.path.join("host", "dcz_service.cpp"), os.path.join("host", "dcz_cli.cpp")]
+CLI = os.path.join(HERE, "dczcli")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror of the reference's service seam + CLI (links libdczhip.so by rpath)."""
+    srcs = [os.path.join(CSRC, f) for f in HOST_SOURCES]
+    hdr = os.path.join(CSRC, "host", "dcz_service.h")
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(f) for f in srcs + [hdr, SO]):
+        return CLI
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-o", CLI] + srcs + ["-L" + HERE, "-ldczhip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
+        build_host(False, verbose)
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -31,6 +52,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    build_host(True, verbose)
     return SO
 
 

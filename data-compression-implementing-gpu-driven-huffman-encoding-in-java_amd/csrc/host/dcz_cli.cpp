@@ -1,0 +1,117 @@
+// dcz_cli.cpp -- command line with the surface of cli/DataCompCLI.java:24-146:
+//   dczcli compress|c|decompress|d <input> <output> [chunkMB]      (default chunk 32 MB, DataCompCLI.java:35)
+// plus `verify <file.dcz>` and `histogram <file>`.  The reference CLI is hard-wired to the CPU service
+// (DataCompCLI.java:62); this one runs the HIP service and fails loudly when no gfx950 device is present.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "dcz_service.h"
+
+static void usage() {
+    std::fprintf(stderr,
+                 "Usage: dczcli <operation> <input> <output> [chunkMB]\n"
+                 "  operations: compress | c | decompress | d | verify <file> | histogram <file>\n");
+}
+
+static std::string fmt_size(long long b) {
+    char buf[64];
+    if (b < 1024) std::snprintf(buf, sizeof buf, "%lld B", b);
+    else if (b < 1024 * 1024) std::snprintf(buf, sizeof buf, "%.2f KB", b / 1024.0);
+    else if (b < 1024LL * 1024 * 1024) std::snprintf(buf, sizeof buf, "%.2f MB", b / (1024.0 * 1024));
+    else std::snprintf(buf, sizeof buf, "%.2f GB", b / (1024.0 * 1024 * 1024));
+    return buf;
+}
+
+static long long file_size(const std::string& p) {
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 ? (long long)st.st_size : -1;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        usage();
+        return 1;
+    }
+    const std::string op = argv[1], in = argv[2];
+    try {
+        if (op == "verify") {
+            datacomp::HipCompressionService svc(32);
+            if (!svc.isAvailable()) throw datacomp::IOError("no gfx950 device available");
+            const bool ok = svc.verifyIntegrity(in);
+            std::printf("%s\n", ok ? "OK" : "CORRUPT");
+            return ok ? 0 : 2;
+        }
+        if (op == "histogram") {
+            datacomp::HipFrequencyService fs;
+            if (!fs.isAvailable()) throw datacomp::IOError("no gfx950 device available");
+            std::ifstream f(in, std::ios::binary | std::ios::ate);
+            if (!f) throw datacomp::IOError("Input file does not exist: " + in);
+            std::vector<uint8_t> d((size_t)f.tellg());
+            f.seekg(0);
+            f.read(reinterpret_cast<char*>(d.data()), (std::streamsize)d.size());
+            const auto h = fs.computeHistogram(d.data(), 0, d.size());
+            for (int i = 0; i < 256; i++) std::printf("%d %lld\n", i, (long long)h[(size_t)i]);
+            return 0;
+        }
+        if (argc < 4) {
+            usage();
+            return 1;
+        }
+        const std::string out = argv[3];
+        int chunkMB = 32;
+        if (argc > 4) {
+            char* end = nullptr;
+            chunkMB = (int)std::strtol(argv[4], &end, 10);
+            if (!end || *end) {
+                std::fprintf(stderr, "Invalid chunk size: %s\n", argv[4]);
+                return 1;
+            }
+        }
+        if (file_size(in) < 0) {
+            std::fprintf(stderr, "Error: Input file does not exist: %s\n", in.c_str());
+            return 1;
+        }
+        datacomp::HipCompressionService svc(chunkMB);
+        if (!svc.isAvailable()) throw datacomp::IOError("no gfx950 device available");
+        const auto t0 = std::chrono::steady_clock::now();
+        auto progress = [](double p) { std::printf("\rProgress: %d%%", (int)(p * 100)); std::fflush(stdout); };
+        if (op == "compress" || op == "c") {
+            std::printf("Compressing...\n  Input:  %s\n  Output: %s\n  Size:   %s\n", in.c_str(), out.c_str(),
+                        fmt_size(file_size(in)).c_str());
+            svc.compress(in, out, progress);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const long long a = file_size(in), b = file_size(out);
+            std::printf("\n\nCompression complete!\n  Original size:   %s\n  Compressed size: %s\n  Compression ratio: %.2f%%\n"
+                        "  Time: %.2f seconds\n  Throughput: %.2f MB/s\n",
+                        fmt_size(a).c_str(), fmt_size(b).c_str(), a ? 100.0 * b / a : 0.0, sec, sec > 0 ? a / 1e6 / sec : 0.0);
+        } else if (op == "decompress" || op == "d") {
+            std::printf("Decompressing...\n  Input:  %s\n  Output: %s\n", in.c_str(), out.c_str());
+            svc.decompress(in, out, progress);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const long long a = file_size(in), b = file_size(out);
+            std::printf("\n\nDecompression complete!\n  Compressed size:   %s\n  Decompressed size: %s\n  Time: %.2f seconds\n"
+                        "  Throughput: %.2f MB/s\n",
+                        fmt_size(a).c_str(), fmt_size(b).c_str(), sec, sec > 0 ? b / 1e6 / sec : 0.0);
+        } else {
+            std::fprintf(stderr, "Unknown operation: %s\n", op.c_str());
+            usage();
+            return 1;
+        }
+        std::printf("\n%s", svc.getLastStageMetrics().summary().c_str());
+        return 0;
+    } catch (const datacomp::IOError& e) {
+        std::fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Unexpected error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,481 @@
+// dcz_service.cpp -- see dcz_service.h.  Host plumbing only: every Huffman stage is a call into include/dcz.h.
+#include "dcz_service.h"
+
+#include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../../include/dcz.h"
+
+namespace datacomp {
+
+namespace {
+
+long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+std::string hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; i++) {
+        s.push_back(d[p[i] >> 4]);
+        s.push_back(d[p[i] & 15]);
+    }
+    return s;
+}
+
+std::string base_name(const std::string& path) {
+    const size_t k = path.find_last_of('/');
+    return k == std::string::npos ? path : path.substr(k + 1);
+}
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw IOError(std::string("GPU compression failed: ") + what + ": " + hipGetErrorString(e));
+}
+
+void dcz_check(dcz_ctx* c, int st, const char* what) {
+    if (st != DCZ_OK)
+        throw IOError(std::string("GPU compression failed: ") + what + ": " + dcz_strerror(st) +
+                      (st == DCZ_E_HIP ? std::string(" (") + dcz_last_error(c) + ")" : std::string()));
+}
+
+struct DevBuf {  // RAII device allocation
+    void* p = nullptr;
+    explicit DevBuf(size_t n) { hip_check(hipMalloc(&p, n ? n : 16), "hipMalloc"); }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+// big-endian DataOutputStream / DataInputStream primitives
+struct BeWriter {
+    std::vector<uint8_t> b;
+    void u32(uint32_t v) { for (int i = 3; i >= 0; i--) b.push_back((uint8_t)(v >> (8 * i))); }
+    void i64(int64_t v) { for (int i = 7; i >= 0; i--) b.push_back((uint8_t)((uint64_t)v >> (8 * i))); }
+    void i16(int16_t v) { b.push_back((uint8_t)((uint16_t)v >> 8)); b.push_back((uint8_t)v); }
+    void raw(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
+};
+
+struct BeReader {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    void need(size_t k) const { if (pos + k > n) throw IOError("Unexpected end of header"); }
+    uint32_t u32() { need(4); uint32_t v = 0; for (int i = 0; i < 4; i++) v = (v << 8) | p[pos++]; return v; }
+    int64_t i64() { need(8); uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[pos++]; return (int64_t)v; }
+    int16_t i16() { need(2); uint16_t v = (uint16_t)((p[pos] << 8) | p[pos + 1]); pos += 2; return (int16_t)v; }
+    void raw(uint8_t* out, size_t k) { need(k); std::memcpy(out, p + pos, k); pos += k; }
+};
+
+std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw IOError("Cannot open " + path);
+    const std::streamsize n = f.tellg();
+    std::vector<uint8_t> v((size_t)n);
+    f.seekg(0);
+    if (n > 0 && !f.read(reinterpret_cast<char*>(v.data()), n)) throw IOError("Cannot read " + path);
+    return v;
+}
+
+}  // namespace
+
+// ---- StageMetrics ---------------------------------------------------------------------------------------------
+void StageMetrics::record(const std::string& stage, long long ns, long long bytes) {
+    Acc& a = acc_[stage];
+    a.ns += ns;
+    a.count += 1;
+    a.bytes += bytes;
+}
+
+long long StageMetrics::time_ns(const std::string& stage) const {
+    auto it = acc_.find(stage);
+    return it == acc_.end() ? 0 : it->second.ns;
+}
+
+std::string StageMetrics::summary() const {
+    long long tot = 0;
+    for (auto& kv : acc_) tot += kv.second.ns;
+    std::ostringstream o;
+    o << "Stage Performance Breakdown:\n";
+    for (auto& kv : acc_) {
+        char line[160];
+        std::snprintf(line, sizeof line, "%-25s: %8.2f ms (%5.1f%%) [%lld runs]\n", kv.first.c_str(), kv.second.ns / 1e6,
+                      tot ? 100.0 * kv.second.ns / tot : 0.0, kv.second.count);
+        o << line;
+    }
+    return o.str();
+}
+
+// ---- SHA-256 (FIPS 180-4) -------------------------------------------------------------------------------------
+namespace {
+const uint32_t KK[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+void sha_block(uint32_t h[8], const uint8_t* p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + KK[i] + w[i];
+        const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+}  // namespace
+
+void sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    const size_t full = n / 64;
+    for (size_t i = 0; i < full; i++) sha_block(h, data + 64 * i);
+    uint8_t tail[128] = {0};
+    const size_t rem = n - 64 * full;
+    if (rem) std::memcpy(tail, data + 64 * full, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem < 56 ? 64 : 128;
+    const uint64_t bits = (uint64_t)n * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha_block(h, tail);
+    if (tl == 128) sha_block(h, tail + 64);
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)(h[i] >> 24);
+        out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(h[i] >> 8);
+        out[4 * i + 3] = (uint8_t)h[i];
+    }
+}
+
+// ---- CompressionHeader ------------------------------------------------------------------------------------------
+std::vector<uint8_t> CompressionHeader::write() const {  // CompressionHeader.java:51-85
+    BeWriter w;
+    w.u32(MAGIC);
+    w.u32(VERSION);
+    w.u32((uint32_t)originalFileName.size());
+    w.raw(reinterpret_cast<const uint8_t*>(originalFileName.data()), originalFileName.size());
+    w.i64(originalFileSize);
+    w.i64(originalTimestamp);
+    w.u32((uint32_t)chunkSizeBytes);
+    w.raw(globalChecksum, 32);
+    w.u32((uint32_t)chunks.size());
+    for (const ChunkMetadata& c : chunks) {
+        w.u32((uint32_t)c.chunkIndex);
+        w.i64(c.originalOffset);
+        w.u32(c.originalSize);
+        w.i64(c.compressedOffset);
+        w.u32(c.compressedSize);
+        w.raw(c.sha256, 32);
+        for (int i = 0; i < 256; i++) w.i16(c.codeLengths[i]);
+    }
+    return w.b;
+}
+
+CompressionHeader CompressionHeader::read(const uint8_t* p, size_t n) {  // CompressionHeader.java:90-144
+    BeReader r{p, n};
+    if (r.u32() != MAGIC) throw IOError("Invalid file format: bad magic number");
+    const uint32_t version = r.u32();
+    if (version != VERSION) throw IOError("Unsupported version: " + std::to_string(version));
+    CompressionHeader h;
+    const uint32_t nameLen = r.u32();
+    if (nameLen > n) throw IOError("Invalid file format: bad name length");
+    h.originalFileName.resize(nameLen);
+    r.raw(reinterpret_cast<uint8_t*>(&h.originalFileName[0]), nameLen);
+    h.originalFileSize = r.i64();
+    h.originalTimestamp = r.i64();
+    h.chunkSizeBytes = (int32_t)r.u32();
+    r.raw(h.globalChecksum, 32);
+    const uint32_t k = r.u32();
+    if ((size_t)k * 572 > n) throw IOError("Unexpected end of header");
+    h.chunks.resize(k);
+    for (uint32_t i = 0; i < k; i++) {
+        ChunkMetadata& c = h.chunks[i];
+        c.chunkIndex = (int32_t)r.u32();
+        c.originalOffset = r.i64();
+        c.originalSize = r.u32();
+        c.compressedOffset = r.i64();
+        c.compressedSize = r.u32();
+        r.raw(c.sha256, 32);
+        for (int j = 0; j < 256; j++) c.codeLengths[j] = r.i16();
+    }
+    return h;
+}
+
+// ---- HipFrequencyService ------------------------------------------------------------------------------------------
+HipFrequencyService::HipFrequencyService(int device) {
+    if (dcz_device_count() > 0 && dcz_ctx_create(device, &ctx_) != DCZ_OK) ctx_ = nullptr;
+}
+HipFrequencyService::~HipFrequencyService() { dcz_ctx_destroy(ctx_); }
+
+std::vector<int64_t> HipFrequencyService::computeHistogram(const uint8_t* data, size_t offset, size_t length) {
+    if (!ctx_) throw std::runtime_error("HIP device not available");
+    std::vector<int64_t> h(256);
+    const int st = dcz_histogram(ctx_, data, offset, length, h.data());
+    if (st != DCZ_OK) throw std::runtime_error(std::string("HIP histogram failed: ") + dcz_strerror(st));
+    return h;
+}
+
+// ---- HipCompressionService ----------------------------------------------------------------------------------------
+HipCompressionService::HipCompressionService(int chunkSizeMB, int device) : device_(device) {
+    if (chunkSizeMB <= 0 || chunkSizeMB > 2047) throw std::invalid_argument("chunk size must be 1..2047 MB");
+    chunkBytes_ = (int64_t)chunkSizeMB * 1024 * 1024;
+    if (batchBytes_ < (size_t)chunkBytes_) batchBytes_ = (size_t)chunkBytes_;
+    if (dcz_device_count() > 0 && dcz_ctx_create(device, &ctx_) != DCZ_OK) ctx_ = nullptr;
+}
+
+HipCompressionService::~HipCompressionService() { close(); }
+
+void HipCompressionService::close() {
+    dcz_ctx_destroy(ctx_);
+    ctx_ = nullptr;
+}
+
+void HipCompressionService::resumeCompression(const std::string&, const std::string&, int, const Progress&) {
+    throw std::logic_error("Resume not yet implemented");  // CpuCompressionService.java:636-641
+}
+
+void HipCompressionService::compress(const std::string& inputPath, const std::string& outputPath,
+                                     const Progress& progress) {
+    if (!ctx_) throw IOError("GPU compression failed: HIP device not available");
+    metrics_ = StageMetrics();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    struct stat st;
+    if (::stat(inputPath.c_str(), &st) != 0) throw IOError("Cannot stat " + inputPath);
+    const int64_t size = st.st_size;
+    const int64_t cb = chunkBytes_;
+    const int64_t numChunks = (size + cb - 1) / cb;
+    std::ifstream fin(inputPath, std::ios::binary);
+    std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
+    if (!fin || !fout) throw IOError("Cannot open input/output file");
+
+    CompressionHeader header;
+    header.originalFileName = base_name(inputPath);
+    header.originalFileSize = size;
+    header.originalTimestamp = (int64_t)st.st_mtim.tv_sec * 1000 + st.st_mtim.tv_nsec / 1000000;  // mtime in ms
+    header.chunkSizeBytes = (int32_t)cb;
+    std::vector<uint8_t> digests;  // 32 bytes per chunk, in index order (CpuCompressionService.java:106-109)
+
+    const int64_t perBatch = std::max<int64_t>(1, (int64_t)batchBytes_ / cb);
+    int64_t compOffset = 0, done = 0;
+    std::vector<uint8_t> host;
+    for (int64_t c0 = 0; c0 < numChunks; c0 += perBatch) {
+        const int64_t c1 = std::min(numChunks, c0 + perBatch);
+        const int64_t bytes = std::min<int64_t>(size - c0 * cb, (c1 - c0) * cb);
+        const int64_t K = c1 - c0;
+        long long t0 = now_ns();
+        host.resize((size_t)bytes);
+        if (!fin.read(reinterpret_cast<char*>(host.data()), bytes)) throw IOError("Cannot read " + inputPath);
+        metrics_.record("File I/O", now_ns() - t0, bytes);
+        t0 = now_ns();
+        for (int64_t k = 0; k < K; k++) {
+            const int64_t off = k * cb, len = std::min<int64_t>(cb, bytes - off);
+            uint8_t d[32];
+            sha256(host.data() + off, (size_t)len, d);
+            digests.insert(digests.end(), d, d + 32);
+        }
+        metrics_.record("Checksum Computation", now_ns() - t0, bytes);
+
+        t0 = now_ns();
+        DevBuf din((size_t)bytes), dout((size_t)bytes + 16), dsize((size_t)K * 4), doff((size_t)K * 8), dlen((size_t)K * 256),
+            dstat((size_t)K * 4), dtot(8);
+        hip_check(hipMemcpy(din.p, host.data(), (size_t)bytes, hipMemcpyHostToDevice), "H2D");
+        dcz_check(ctx_, dcz_compress_blocks(ctx_, din.p, (size_t)bytes, (size_t)cb, dout.p, (size_t)bytes + 16,
+                                            dsize.as<uint32_t>(), doff.as<uint64_t>(), dlen.as<uint8_t>(),
+                                            dstat.as<int32_t>(), dtot.as<uint64_t>(), nullptr),
+                  "dcz_compress_blocks");
+        hip_check(hipDeviceSynchronize(), "sync");
+        std::vector<uint32_t> sizes((size_t)K);
+        std::vector<int32_t> stat((size_t)K);
+        std::vector<uint8_t> lens((size_t)K * 256);
+        uint64_t total = 0;
+        hip_check(hipMemcpy(sizes.data(), dsize.p, (size_t)K * 4, hipMemcpyDeviceToHost), "D2H sizes");
+        hip_check(hipMemcpy(stat.data(), dstat.p, (size_t)K * 4, hipMemcpyDeviceToHost), "D2H status");
+        hip_check(hipMemcpy(lens.data(), dlen.p, (size_t)K * 256, hipMemcpyDeviceToHost), "D2H lens");
+        hip_check(hipMemcpy(&total, dtot.p, 8, hipMemcpyDeviceToHost), "D2H total");
+        for (int64_t k = 0; k < K; k++)
+            if (stat[(size_t)k] != DCZ_OK)
+                throw IOError("GPU compression failed: chunk " + std::to_string(c0 + k) + ": " + dcz_strerror(stat[(size_t)k]));
+        std::vector<uint8_t> payload((size_t)total);
+        if (total) hip_check(hipMemcpy(payload.data(), dout.p, (size_t)total, hipMemcpyDeviceToHost), "D2H payload");
+        metrics_.record("Encoding", now_ns() - t0, bytes);
+
+        t0 = now_ns();
+        fout.write(reinterpret_cast<const char*>(payload.data()), (std::streamsize)payload.size());
+        metrics_.record("File I/O", now_ns() - t0, (long long)total);
+        for (int64_t k = 0; k < K; k++) {
+            ChunkMetadata m;
+            m.chunkIndex = (int32_t)(c0 + k);
+            m.originalOffset = (c0 + k) * cb;
+            m.originalSize = (uint32_t)std::min<int64_t>(cb, size - (c0 + k) * cb);
+            m.compressedOffset = compOffset;
+            m.compressedSize = sizes[(size_t)k];
+            std::memcpy(m.sha256, &digests[(size_t)(c0 + k) * 32], 32);
+            for (int i = 0; i < 256; i++) m.codeLengths[i] = (int16_t)lens[(size_t)k * 256 + i];
+            header.chunks.push_back(m);
+            compOffset += sizes[(size_t)k];
+            done++;
+            if (progress) progress((double)done / (double)numChunks);  // CpuCompressionService.java:111-114
+        }
+    }
+    const long long t0 = now_ns();
+    sha256(digests.data(), digests.size(), header.globalChecksum);  // digest of digests (:106-109, :126)
+    const int64_t footerStart = compOffset;
+    const std::vector<uint8_t> hb = header.write();
+    fout.write(reinterpret_cast<const char*>(hb.data()), (std::streamsize)hb.size());
+    BeWriter ptr;
+    ptr.i64(footerStart);  // raf.writeLong(footerStart), CpuCompressionService.java:174
+    fout.write(reinterpret_cast<const char*>(ptr.b.data()), 8);
+    if (!fout) throw IOError("Cannot write " + outputPath);
+    metrics_.record("Header Write", now_ns() - t0, 0);
+}
+
+void HipCompressionService::decodeAll(const std::string& path, const std::function<void(const uint8_t*, size_t)>& sink,
+                                      const Progress& progress, CompressionHeader* header_out) {
+    if (!ctx_) throw IOError("GPU decompression failed: HIP device not available");
+    metrics_ = StageMetrics();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    long long t0 = now_ns();
+    const std::vector<uint8_t> file = read_file(path);
+    metrics_.record("File I/O", now_ns() - t0, (long long)file.size());
+    const size_t total = file.size();
+    // probe order of CpuCompressionService.decompress: header-first from the first <= 4096 bytes (:338-358), else the
+    // footer through the trailing pointer with the 0 <= ptr < size-8 check (:366-388)
+    CompressionHeader header;
+    size_t dataStart = 0;
+    bool parsed = false;
+    {
+        std::vector<uint8_t> probe(std::min<size_t>(64 * 1024, total), 0);
+        std::memcpy(probe.data(), file.data(), std::min<size_t>(4096, probe.size()));
+        try {
+            header = CompressionHeader::read(probe.data(), probe.size());
+            size_t sum = 0;
+            for (auto& c : header.chunks) sum += c.compressedSize;
+            dataStart = total - sum;
+            parsed = true;
+        } catch (const IOError&) {
+        }
+    }
+    if (!parsed) {
+        if (total < 8) throw IOError("Invalid file format: file too small");
+        BeReader r{file.data() + total - 8, 8};
+        const int64_t ptr = r.i64();
+        if (ptr < 0 || (uint64_t)ptr >= total - 8) throw IOError("Invalid footer position: " + std::to_string(ptr));
+        header = CompressionHeader::read(file.data() + ptr, total - 8 - (size_t)ptr);
+        dataStart = 0;
+    }
+    const size_t numChunks = header.chunks.size();
+    const size_t per = std::max<size_t>(1, batchBytes_ / (size_t)std::max(1, header.chunkSizeBytes));
+    size_t done = 0;
+    for (size_t c0 = 0; c0 < numChunks; c0 += per) {
+        const size_t c1 = std::min(numChunks, c0 + per), K = c1 - c0;
+        t0 = now_ns();
+        std::vector<uint8_t> blob;
+        std::vector<uint64_t> offs(K);
+        std::vector<uint32_t> sizes(K), origs(K);
+        std::vector<uint8_t> lens(K * 256);
+        size_t stride = 16;
+        for (size_t k = 0; k < K; k++) {
+            const ChunkMetadata& c = header.chunks[c0 + k];
+            const size_t beg = dataStart + (size_t)c.compressedOffset;
+            if (beg + c.compressedSize > total)
+                throw IOError("Chunk decompression failed: truncated payload in chunk " + std::to_string(c.chunkIndex));
+            offs[k] = blob.size();
+            sizes[k] = c.compressedSize;
+            origs[k] = c.originalSize;
+            blob.insert(blob.end(), file.begin() + (long)beg, file.begin() + (long)(beg + c.compressedSize));
+            for (int i = 0; i < 256; i++) {
+                if (c.codeLengths[i] < 0 || c.codeLengths[i] > 32) throw IOError("Chunk decompression failed: bad code length table");
+                lens[k * 256 + i] = (uint8_t)c.codeLengths[i];
+            }
+            stride = std::max<size_t>(stride, c.originalSize);
+        }
+        stride = (stride + 15) & ~(size_t)15;
+        blob.resize(blob.size() + 16, 0);
+        DevBuf dcomp(blob.size()), doff(K * 8), dsize(K * 4), dorig(K * 4), dlen(K * 256), dout(K * stride + 16), dstat(K * 4),
+            derr(K * 8);
+        hip_check(hipMemcpy(dcomp.p, blob.data(), blob.size(), hipMemcpyHostToDevice), "H2D payload");
+        hip_check(hipMemcpy(doff.p, offs.data(), K * 8, hipMemcpyHostToDevice), "H2D");
+        hip_check(hipMemcpy(dsize.p, sizes.data(), K * 4, hipMemcpyHostToDevice), "H2D");
+        hip_check(hipMemcpy(dorig.p, origs.data(), K * 4, hipMemcpyHostToDevice), "H2D");
+        hip_check(hipMemcpy(dlen.p, lens.data(), K * 256, hipMemcpyHostToDevice), "H2D");
+        dcz_check(ctx_, dcz_decompress_blocks(ctx_, dcomp.p, blob.size(), doff.as<uint64_t>(), dsize.as<uint32_t>(),
+                                              dorig.as<uint32_t>(), dlen.as<uint8_t>(), K, stride, dout.p, dstat.as<int32_t>(),
+                                              derr.as<int64_t>(), nullptr),
+                  "dcz_decompress_blocks");
+        hip_check(hipDeviceSynchronize(), "sync");
+        std::vector<int32_t> stat(K);
+        std::vector<int64_t> epos(K);
+        hip_check(hipMemcpy(stat.data(), dstat.p, K * 4, hipMemcpyDeviceToHost), "D2H");
+        hip_check(hipMemcpy(epos.data(), derr.p, K * 8, hipMemcpyDeviceToHost), "D2H");
+        for (size_t k = 0; k < K; k++) {
+            if (stat[k] == DCZ_E_BADSTREAM)  // TableBasedHuffmanDecoder.java:109-111 wrapped by CpuCompressionService.java:469-471
+                throw IOError("Chunk decompression failed: Huffman decode error at position " + std::to_string(epos[k]));
+            if (stat[k] != DCZ_OK) throw IOError(std::string("Chunk decompression failed: ") + dcz_strerror(stat[k]));
+        }
+        std::vector<uint8_t> out(K * stride);
+        hip_check(hipMemcpy(out.data(), dout.p, K * stride, hipMemcpyDeviceToHost), "D2H decoded");
+        metrics_.record("Decoding", now_ns() - t0, (long long)(K * stride));
+        for (size_t k = 0; k < K; k++) {
+            const ChunkMetadata& c = header.chunks[c0 + k];
+            t0 = now_ns();
+            uint8_t d[32];
+            sha256(out.data() + k * stride, c.originalSize, d);
+            if (std::memcmp(d, c.sha256, 32) != 0) {  // CpuCompressionService.java:536-550
+                std::ostringstream o;
+                o << "Checksum mismatch in chunk " << c.chunkIndex << ":\n  Expected: " << hex(c.sha256, 32)
+                  << "\n  Actual:   " << hex(d, 32) << "\n  Chunk size: " << c.originalSize
+                  << " bytes\n  Compressed size: " << c.compressedSize << " bytes\n  Compressed offset: "
+                  << c.compressedOffset;
+                throw IOError(o.str());
+            }
+            metrics_.record("Checksum Verification", now_ns() - t0, c.originalSize);
+            sink(out.data() + k * stride, c.originalSize);
+            done++;
+            if (progress) progress((double)done / (double)numChunks);
+        }
+    }
+    if (header_out) *header_out = header;
+}
+
+void HipCompressionService::decompress(const std::string& inputPath, const std::string& outputPath,
+                                       const Progress& progress) {
+    std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
+    if (!fout) throw IOError("Cannot open " + outputPath);
+    decodeAll(inputPath, [&](const uint8_t* p, size_t n) { fout.write(reinterpret_cast<const char*>(p), (std::streamsize)n); },
+              progress, nullptr);
+    if (!fout) throw IOError("Cannot write " + outputPath);
+}
+
+bool HipCompressionService::verifyIntegrity(const std::string& compressedPath) {
+    // A real verification (the reference only scans the last 64 KiB for a header: CpuCompressionService.java:652-694).
+    try {
+        CompressionHeader h;
+        decodeAll(compressedPath, [](const uint8_t*, size_t) {}, {}, &h);
+        std::vector<uint8_t> dig;
+        for (auto& c : h.chunks) dig.insert(dig.end(), c.sha256, c.sha256 + 32);
+        uint8_t g[32];
+        sha256(dig.data(), dig.size(), g);
+        return std::memcmp(g, h.globalChecksum, 32) == 0;
+    } catch (const std::exception&) {
+        return false;
+    }
+}
+
+}  // namespace datacomp

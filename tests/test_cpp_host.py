@@ -1,0 +1,75 @@
+"""The C++ host mirror of the reference's service seam (csrc/host/dcz_service.cpp + dczcli, the stand-in for the
+Java classes that cannot be compiled here): same container bytes as the Python mirror and the oracle, same
+error behaviour, same CLI surface as cli/DataCompCLI.java:24-146."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "data-compression-implementing-gpu-driven-huffman-encoding-in-java_amd", "dczcli")
+
+
+def run(*args):
+    return subprocess.run([CLI, *map(str, args)], capture_output=True, text=True, timeout=300)
+
+
+def test_cli_is_built_and_fails_loudly_without_a_gpu():
+    assert os.path.exists(CLI), "dczcli missing: run python __graft_entry__.py"
+    r = run()
+    assert r.returncode == 1 and "Usage: dczcli" in r.stderr
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        src = os.path.join(ROOT, "tests", "golden", "test_small.bin")
+        r = run("compress", src, "/tmp/dcz_should_not_exist.dcz", 1)
+        assert r.returncode == 1 and "no gfx950 device" in r.stderr  # no CPU fallback in the product
+
+
+@pytest.mark.gpu
+def test_cli_round_trip_matches_python_mirror_and_oracle(svc, orc, pkg, tmp_path):
+    data = np.concatenate([orc.gen_text(4, 0, 2_500_000), orc.java_random_bytes(4, 700_001),
+                           orc.gen_lowentropy(4, 0, 900_000)])
+    src = tmp_path / "mixed.bin"
+    src.write_bytes(data.tobytes())
+    r = run("compress", src, tmp_path / "cpp.dcz", 1)
+    assert r.returncode == 0, r.stderr
+    assert "Compression complete!" in r.stdout and "Progress: 100%" in r.stdout
+    svc.compress(src, tmp_path / "py.dcz")  # same file name and mtime -> the containers must be identical
+    cpp = (tmp_path / "cpp.dcz").read_bytes()
+    assert cpp == (tmp_path / "py.dcz").read_bytes()
+    pay, sizes, offs, lens = orc.compress_blocks(data, 1 << 20)
+    assert cpp[: pay.size] == pay.tobytes()
+    header, _ = pkg.container.locate_header(cpp)
+    assert [c.compressed_size for c in header.chunks] == sizes.tolist()
+    assert header.chunks[2].sha256 == orc.sha256(data[2 << 20:3 << 20])
+    # decompress with the C++ host a file written by the Python mirror, and the other way round
+    r = run("d", tmp_path / "py.dcz", tmp_path / "back_cpp.bin")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "back_cpp.bin").read_bytes() == data.tobytes()
+    svc.decompress(tmp_path / "cpp.dcz", tmp_path / "back_py.bin")
+    assert (tmp_path / "back_py.bin").read_bytes() == data.tobytes()
+    assert run("verify", tmp_path / "cpp.dcz").returncode == 0
+    bad = bytearray(cpp)
+    bad[12345] ^= 1
+    (tmp_path / "bad.dcz").write_bytes(bytes(bad))
+    assert run("verify", tmp_path / "bad.dcz").returncode == 2
+    r = run("decompress", tmp_path / "bad.dcz", tmp_path / "x.bin")
+    assert r.returncode == 1 and ("Checksum mismatch in chunk 0" in r.stderr or "Huffman decode error at position" in r.stderr)
+    # empty input: no chunks, 68 + nameLen + 8 bytes (CpuCompressionServiceTest.java:81-95)
+    (tmp_path / "empty.txt").write_bytes(b"")
+    assert run("c", tmp_path / "empty.txt", tmp_path / "empty.dcz", 1).returncode == 0
+    assert (tmp_path / "empty.dcz").stat().st_size == 85
+    assert run("d", tmp_path / "empty.dcz", tmp_path / "empty.out").returncode == 0
+    assert (tmp_path / "empty.out").read_bytes() == b""
+    # FrequencyService through the C++ host
+    r = run("histogram", src)
+    h = np.array([int(line.split()[1]) for line in r.stdout.strip().splitlines()])
+    assert (h == np.bincount(data, minlength=256)).all()
+    # missing input / bad chunk size behave like DataCompCLI.java:38-52
+    assert run("c", tmp_path / "nope.bin", tmp_path / "o.dcz").returncode == 1
+    assert "Invalid chunk size" in run("c", src, tmp_path / "o.dcz", "abc").stderr
