@@ -66,7 +66,7 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4S_NS 1
 #endif
 
-template <int W, int NS, int OC, int PV>
+template <int W, int NS, int OC, int PV, bool MULTI>
 struct DecLds {
     static_assert(W >= 64 && W % 64 == 0, "whole waves only");
     static constexpr int NSUB = W * NS;
@@ -81,6 +81,11 @@ struct DecLds {
     static constexpr int PRIV_DW = PRIV ? PRIV / 4 + 1 : 0;  // odd dword stride: conflict-free lane-strided access
     uint32_t priv[W * PRIV_DW + 4];
     uint16_t table[1 << TB];
+    // short-code kernel (MULTI): per TB-bit window, the maximal run of complete codewords inside it
+    //   mcount: (symbols << 4) | bits                      -> phase A skips several symbols per lookup
+    //   mout:   s0 | s1 << 8 | s2 << 16 | bits << 24 | symbols << 28 (first <= 3 symbols) -> phase B
+    uint16_t mcount[MULTI ? (1 << TB) : 1];
+    uint32_t mout[MULTI ? (1 << TB) : 1];
     uint16_t exits[NSUB];
     unsigned long long lim[40];  // lim[l] = (first[l] + cnt[l]) << (32 - l): exclusive left-aligned upper bound of length l
     uint32_t first[34];
@@ -116,8 +121,8 @@ __device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t np
 // length, and everything below the TB+1 range was already answered by the table, so the length of window w is
 // the first l > TB with w < lim[l] (64-bit, left-aligned); four independent LDS reads per step.  No match = no
 // codeword (the reference's "decode error at position i").
-template <int W, int NS, int OC, int PV>
-__device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV>& L, uint32_t win32) {
+template <int W, int NS, int OC, int PV, bool MULTI>
+__device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV, MULTI>& L, uint32_t win32) {
     const uint32_t maxlen = L.maxlen;
     const unsigned long long w = win32;
     for (uint32_t l = TB + 1; l <= maxlen; l += 4) {
@@ -162,8 +167,8 @@ __device__ __forceinline__ void copy_run(const uint32_t* pv, uint32_t so, uint32
     }
 }
 
-template <int W, int NS, int OC, int PV>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC, PV>& L, uint32_t& total) {
+template <int W, int NS, int OC, int PV, bool MULTI>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC, PV, MULTI>& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
@@ -203,7 +208,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
     return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
 }
 
-template <int W, int NS, int OC, int PV>
+template <int W, int NS, int OC, int PV, bool MULTI>
 __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
                                                long long* __restrict__ d_errpos) {
-    using LdsT = DecLds<W, NS, OC, PV>;
+    using LdsT = DecLds<W, NS, OC, PV, MULTI>;
     __shared__ LdsT L;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
@@ -284,6 +289,32 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     const uint32_t orig = d_orig_size[b];
     const unsigned long long coff = d_comp_off[b];
     const uint32_t csize = d_comp_size[b];
+    // Two instantiations of this kernel are launched over the same blocks: the short-code one (MULTI, tables that
+    // yield several symbols per lookup) takes blocks that average < 6.5 bits per symbol, the other one the rest.
+    {
+        const bool short_codes = (unsigned long long)csize * 16ull < (unsigned long long)orig * 13ull;
+        if (short_codes != MULTI) return;  // workgroup-uniform; the other launch owns this block
+    }
+    if constexpr (MULTI) {
+        __syncthreads();  // L.table complete
+        for (int idx = tid; idx < (1 << TB); idx += W) {
+            uint32_t pos = 0, cnt = 0, out = 0, bits3 = 0, cnt3 = 0;
+            while (pos < (uint32_t)TB) {
+                const uint32_t e = L.table[((uint32_t)idx << pos) & ((1u << TB) - 1u)];
+                const uint32_t len = e >> 8;
+                if (e == 0 || len > (uint32_t)TB - pos) break;  // escape, or the codeword leaves the window
+                if (cnt < 3) {
+                    out |= (e & 0xFFu) << (8 * cnt);
+                    bits3 = pos + len;
+                    cnt3 = cnt + 1;
+                }
+                pos += len;
+                cnt++;
+            }
+            L.mcount[idx] = (uint16_t)(cnt ? ((cnt << 4) | pos) : 0u);
+            L.mout[idx] = cnt3 ? (out | (bits3 << 24) | (cnt3 << 28)) : 0u;
+        }
+    }
     uint8_t* const oblk = out + (uint64_t)b * out_stride;
     const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
     // virtual byte 0 = 16-byte aligned address at or below the payload start
@@ -315,6 +346,8 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
     const uint32_t nbase = 8u * top_addr + 31u;  // npos = nbase - pos
     const uint32_t tbl_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.table[0]));
+    const uint32_t mcount_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.mcount[0]));
+    const uint32_t mout_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.mout[0]));
 
     // prefetch registers for the window at wchunk0 (+ the look-ahead chunk, last thread only)
     uint4 pre[NCH];
@@ -398,7 +431,37 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                 }
                 any |= np[s] > nl[s];
             }
-            while (any) {
+            if constexpr (MULTI) {
+                // short codes: while at least TB bits remain before the limit, one lookup in mcount consumes every
+                // complete codeword of the window (all of them start before the limit); the last < TB bits and
+                // escapes go one symbol at a time
+                static_assert(!MULTI || NS == 1, "short-code kernel: one subsequence per thread");
+                while (any) {
+                    const unsigned long long two = fetch64(np[0]);
+                    const uint32_t off = table_off(two, np[0]);
+                    const bool a = np[0] > nl[0];
+                    const bool far = a && (np[0] - nl[0] >= (uint32_t)TB);
+                    uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)((far ? mcount_addr : tbl_addr) + off);
+                    uint32_t bits = far ? (e & 15u) : (e >> 8);
+                    uint32_t cnt = far ? (e >> 4) : 1u;
+                    if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
+                        if (a && e == 0) {
+                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            bits = e >> 8;
+                            cnt = 1;
+                            if (e == 0) {
+                                bad[0] = true;
+                                nl[0] = 0xFFFFFFFFu;
+                            }
+                        }
+                    }
+                    const bool a2 = np[0] > nl[0];
+                    np[0] -= a2 ? bits : 0u;
+                    nsym[0] += a2 ? cnt : 0u;
+                    any = np[0] > nl[0];
+                }
+            }
+            while (!MULTI && any) {
                 unsigned long long two[NS];
                 uint32_t e[NS];
 #pragma unroll
@@ -414,7 +477,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                         if (e[s] == 0 && np[s] > nl[s]) {
-                            e[s] = slow_lookup<W, NS, OC, PV>(L, window32(two[s], np[s]));
+                            e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two[s], np[s]));
                             if (e[s] == 0) {  // no codeword matches: stop this stream
                                 bad[s] = true;
                                 nl[s] = 0xFFFFFFFFu;
@@ -456,7 +519,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
         for (int s = 0; s < NS; s++) tsum += nsym[s];
         uint32_t tw = 0;
-        const uint32_t o = block_exclusive_scan<W, NS, OC, PV>(tsum, L, tw);
+        const uint32_t o = block_exclusive_scan<W, NS, OC, PV, MULTI>(tsum, L, tw);
         const uint32_t remaining = orig - produced;
         {
             uint32_t oo = o;
@@ -513,7 +576,35 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                 }
                 any |= oi[s] < ce[s];
             }
-            while (any) {
+            if constexpr (MULTI) {
+                // short codes: up to 3 symbols per lookup while at least 3 symbols of this chunk are still owed
+                while (any) {
+                    const unsigned long long two = fetch64(np[0]);
+                    const uint32_t off = table_off(two, np[0]);  // byte offset of the u16 entry = 2 * index
+                    const bool a = oi[0] < ce[0];
+                    const bool big = a && (ce[0] - oi[0] >= 3u);
+                    uint32_t e;
+                    if (big) e = *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(mout_addr + 2u * off);
+                    else e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + off);
+                    uint32_t bits = big ? ((e >> 24) & 15u) : (e >> 8);
+                    uint32_t cnt = big ? (e >> 28) : 1u;
+                    if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
+                        if (a && e == 0) {
+                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            bits = e >> 8;
+                            cnt = 1;
+                        }
+                    }
+                    const uint32_t t = oi[0] + tshift;
+                    if (a) ob[opad(t)] = (uint8_t)e;
+                    if (a && cnt > 1u) ob[opad(t + 1u)] = (uint8_t)(e >> 8);
+                    if (a && cnt > 2u) ob[opad(t + 2u)] = (uint8_t)(e >> 16);
+                    np[0] -= a ? bits : 0u;
+                    oi[0] += a ? cnt : 0u;
+                    any = oi[0] < ce[0];
+                }
+            }
+            while (!MULTI && any) {
                 unsigned long long two[NS];
                 uint32_t e[NS];
 #pragma unroll
@@ -528,7 +619,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                 if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC, PV>(L, window32(two[s], np[s]));
+                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two[s], np[s]));
                 }
                 any = false;
 #pragma unroll
@@ -601,11 +692,15 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     }();
     if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes, off, d_comp_size,
-                           d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false>), dim3(K), dim3(DCZ_K4_W), 0, s,
+                           d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4_OC, 0, true>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes,
+                           off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
-        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off, d_comp_size,
-                           d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false>), dim3(K), dim3(1024), 0, s, d_comp,
+                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
+                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
     }
 }
 
