@@ -54,13 +54,19 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4_NS 1      // subsequences per thread, many-blocks kernel
 #endif
 #ifndef DCZ_K4_PRIV
-#define DCZ_K4_PRIV 0    // symbols a subsequence may park in LDS during phase A, many-blocks kernel (0 = off: the
-#endif                   // extra LDS costs more occupancy than the second decode costs time; measured)
+#define DCZ_K4_PRIV 64   // symbols a subsequence parks in REGISTERS during phase A (PRIV/4 VGPRs), so that phase B
+#endif                   // copies them into the tile instead of decoding again; 0 = off
 #ifndef DCZ_K4S_PRIV
-#define DCZ_K4S_PRIV 64  // few-blocks kernel: one workgroup per CU anyway, so LDS is free and parking pays
+#define DCZ_K4S_PRIV 64
+#endif
+#ifndef DCZ_K4M_OC
+#define DCZ_K4M_OC 8192  // short-code instantiation, many-blocks kernel
 #endif
 #ifndef DCZ_K4S_OC
 #define DCZ_K4S_OC 32768 // few-blocks kernel (one 1024-thread workgroup per block owns the CU: use its LDS)
+#endif
+#ifndef DCZ_K4_OCX
+#define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
 #endif
 #ifndef DCZ_K4S_NS
 #define DCZ_K4S_NS 1
@@ -74,12 +80,14 @@ struct DecLds {
     static constexpr int STRIDE = STRIPE + 3;    // + 2 look-ahead dwords + 1 pad (odd => conflict-free)
     __attribute__((aligned(16))) uint32_t cbuf[W * STRIDE + 4];
     // logical byte i of the output tile lives at i + 4 * (i >> 6): one pad dword per 64 bytes
-    __attribute__((aligned(16))) uint32_t outbuf[(OC + OC / 16) / 4 + 16];
-    // phase A parks the symbols of each subsequence here; after the fixed point the LAST decode of a
-    // subsequence started at its true entry, so phase B can copy them instead of decoding again
+    static constexpr int CAP = OC + DCZ_K4_OCX;  // tile capacity in bytes
+    __attribute__((aligned(16))) uint32_t outbuf[(CAP + CAP / 16) / 4 + 32];
+    // Phase A parks the first PRIV symbols of each subsequence in registers; after the fixed point the LAST decode
+    // of a subsequence started at its true entry, so phase B ORs them into the (zeroed) tile as whole dwords
+    // instead of decoding again.
     static constexpr int PRIV = (NS == 1) ? PV : 0;
-    static constexpr int PRIV_DW = PRIV ? PRIV / 4 + 1 : 0;  // odd dword stride: conflict-free lane-strided access
-    uint32_t priv[W * PRIV_DW + 4];
+    static_assert(PRIV % 4 == 0, "whole registers");
+    uint32_t cend_vote;
     uint16_t table[1 << TB];
     // short-code kernel (MULTI): per TB-bit window, the maximal run of complete codewords inside it
     //   mcount: (symbols << 4) | bits                      -> phase A skips several symbols per lookup
@@ -136,37 +144,6 @@ __device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV, MULT
     return 0;
 }
 
-// Copy cnt bytes from a thread's private area (byte offset so) to logical tile byte dlog: bytes up to the next
-// tile dword, then whole dwords assembled with v_alignbyte, then the remaining bytes.
-__device__ __forceinline__ void copy_run(const uint32_t* pv, uint32_t so, uint32_t* tile, uint32_t dlog, uint32_t cnt) {
-    const uint8_t* pb = reinterpret_cast<const uint8_t*>(pv);
-    uint8_t* tb = reinterpret_cast<uint8_t*>(tile);
-    while (cnt > 0 && (dlog & 3u) != 0u) {
-        tb[opad(dlog)] = pb[so];
-        so++;
-        dlog++;
-        cnt--;
-    }
-    uint32_t q = so >> 2;
-    const uint32_t sel = so & 3u;
-    uint32_t lo = pv[q];
-    while (cnt >= 4) {
-        const uint32_t hi = pv[q + 1];  // at most one dword past the parked symbols: the stride's pad dword
-        tile[(dlog >> 2) + (dlog >> 6)] = __builtin_amdgcn_alignbyte(hi, lo, sel);
-        lo = hi;
-        q++;
-        so += 4;
-        dlog += 4;
-        cnt -= 4;
-    }
-    while (cnt > 0) {
-        tb[opad(dlog)] = pb[so];
-        so++;
-        dlog++;
-        cnt--;
-    }
-}
-
 template <int W, int NS, int OC, int PV, bool MULTI>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC, PV, MULTI>& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
@@ -221,6 +198,17 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
+
+    // ---- block geometry ----
+    const uint32_t orig = d_orig_size[b];
+    const unsigned long long coff = d_comp_off[b];
+    const uint32_t csize = d_comp_size[b];
+    // Two instantiations of this kernel are launched over the same blocks: the short-code one (MULTI, tables that
+    // yield several symbols per lookup) takes blocks that average < 6.5 bits per symbol, the other one the rest.
+    {
+        const bool short_codes = (unsigned long long)csize * 16ull < (unsigned long long)orig * 13ull;
+        if (short_codes != MULTI) return;  // workgroup-uniform; the other launch owns this block
+    }
 
     // ---- per-block tables (rebuildCodes: CpuCompressionService.java:582-586 -> CanonicalHuffman.java:99-132) ----
     if (tid < 34) L.cnt[tid] = 0;
@@ -285,15 +273,8 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         L.table[idx] = (uint16_t)e;
     }
 
-    // ---- block geometry ----
-    const uint32_t orig = d_orig_size[b];
-    const unsigned long long coff = d_comp_off[b];
-    const uint32_t csize = d_comp_size[b];
-    // Two instantiations of this kernel are launched over the same blocks: the short-code one (MULTI, tables that
-    // yield several symbols per lookup) takes blocks that average < 6.5 bits per symbol, the other one the rest.
-    {
-        const bool short_codes = (unsigned long long)csize * 16ull < (unsigned long long)orig * 13ull;
-        if (short_codes != MULTI) return;  // workgroup-uniform; the other launch owns this block
+    if constexpr (LdsT::PRIV > 0) {  // the tile is OR-ed into: start from zero
+        for (int i = tid; i < (int)(sizeof(L.outbuf) / 4); i += W) L.outbuf[i] = 0;
     }
     if constexpr (MULTI) {
         __syncthreads();  // L.table complete
@@ -325,7 +306,7 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
     const unsigned long long vhi = (unsigned long long)skew + csize;  // one past the last valid virtual byte
     (void)comp_bytes;
 
-    // Park symbols only when a 32-byte subsequence is expected to hold at most 3/4 of the private capacity
+    // Park symbols only when a 32-byte subsequence is expected to hold at most 3/4 of the register capacity
     // (expected symbols = 32 * orig / csize from the block's own sizes); otherwise too many subsequences
     // overflow and are decoded twice anyway.
     const bool park = LdsT::PRIV > 0 &&
@@ -339,8 +320,10 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 
     uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe (descending)
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.outbuf);
-    uint32_t* const pv = &L.priv[(uint32_t)tid * (uint32_t)LdsT::PRIV_DW];  // this thread's private symbol area
-    uint8_t* const pvb = reinterpret_cast<uint8_t*>(pv);
+    constexpr int NR = LdsT::PRIV > 0 ? LdsT::PRIV / 4 : 1;
+    uint32_t R[NR];  // parked symbols, 4 per register, first symbol in the low byte
+#pragma unroll
+    for (int j = 0; j < NR; j++) R[j] = 0;
     // descending-position origin: logical dword j of the stripe lives at cb[STRIPE + 1 - j]
     const uint32_t top_addr =
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
@@ -461,6 +444,39 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
                     any = np[0] > nl[0];
                 }
             }
+            if constexpr (LdsT::PRIV > 0) {
+                if (park) {  // workgroup-uniform
+                    // Fully unrolled so that symbol k lands in a compile-time register; leaves (wave-uniformly) as
+                    // soon as no lane is active.  Lanes that do not decode this round keep their registers.
+                    if (need[0]) {
+#pragma unroll
+                        for (int j = 0; j < NR; j++) R[j] = 0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < LdsT::PRIV; k++) {
+                        const bool a = np[0] > nl[0];
+                        if (__builtin_amdgcn_ballot_w64(a) == 0ull) break;
+                        const unsigned long long two = fetch64(np[0]);
+                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
+                                                                                                   table_off(two, np[0]));
+                        if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
+                            if (a && e == 0) {
+                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                                if (e == 0) {
+                                    bad[0] = true;
+                                    nl[0] = 0xFFFFFFFFu;
+                                }
+                            }
+                        }
+                        const bool a2 = np[0] > nl[0];
+                        e = a2 ? e : 0u;
+                        R[k >> 2] |= (e & 0xFFu) << (8 * (k & 3));
+                        np[0] -= e >> 8;
+                        nsym[0] += a2 ? 1u : 0u;
+                    }
+                    any = np[0] > nl[0];
+                }
+            }
             while (!MULTI && any) {
                 unsigned long long two[NS];
                 uint32_t e[NS];
@@ -488,9 +504,6 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     const bool a = np[s] > nl[s];
-                    if constexpr (LdsT::PRIV > 0) {
-                        if (park && a && nsym[s] < (uint32_t)LdsT::PRIV) pvb[nsym[s]] = (uint8_t)e[s];
-                    }
                     np[s] -= a ? (e[s] >> 8) : 0u;
                     nsym[s] += a ? 1u : 0u;
                     any |= np[s] > nl[s];
@@ -560,7 +573,21 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
         }
         for (uint32_t cbase = 0; cbase < lim;) {
             uint32_t cc = lim - cbase;
-            if (cc > (uint32_t)OC - ocarry) cc = (uint32_t)OC - ocarry;
+            const uint32_t room = (uint32_t)LdsT::CAP - ocarry;
+            if (cc > room) {  // workgroup-uniform: the rest of the window does not fit one flush
+                cc = room;
+                if constexpr (LdsT::PRIV > 0) {
+                    if (park) {  // end the flush on a subsequence boundary: no parked run straddles it
+                        if (tid == 0) L.cend_vote = 0;
+                        __syncthreads();
+                        const uint32_t end0 = o + nsym[0];
+                        if (end0 > cbase + room / 2u && end0 <= cbase + room) atomicMax(&L.cend_vote, end0);
+                        __syncthreads();
+                        const uint32_t v = L.cend_vote;
+                        if (v != 0u) cc = v - cbase;
+                    }
+                }
+            }
             const uint32_t cend = cbase + cc;
             const uint32_t tshift = ocarry - cbase;  // tile index = window symbol index + tshift
             uint32_t ce[NS];                         // this chunk's end for each stream
@@ -569,9 +596,24 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             for (int s = 0; s < NS; s++) {
                 ce[s] = oe[s] < cend ? oe[s] : cend;
                 if constexpr (LdsT::PRIV > 0) {
-                    if (park && nsym[s] <= (uint32_t)LdsT::PRIV) {  // whole subsequence is parked: copy this chunk's part of it
-                        if (oi[s] < ce[s]) copy_run(pv, oi[s] - o, L.outbuf, oi[s] + tshift, ce[s] - oi[s]);
-                        oi[s] = ce[s] > oi[s] ? ce[s] : oi[s];
+                    static_assert(LdsT::PRIV <= 64, "a parked run crosses at most one tile pad");
+                    // a wholly parked subsequence that lies inside this flush: OR its registers into the tile,
+                    // shifted to the byte phase of its first symbol (bytes outside the run are zero)
+                    if (park && nsym[s] <= (uint32_t)LdsT::PRIV && oi[s] == o && oi[s] < oe[s] && oe[s] <= cend) {
+                        const uint32_t d = oi[s] + tshift;  // logical tile byte of the first symbol
+                        const uint32_t sh = d & 3u, dw = d >> 2;
+                        uint32_t* const tp = &L.outbuf[dw + (dw >> 4)];
+                        const uint32_t kc = 16u - (dw & 15u);  // first register index past the next pad dword
+                        const uint32_t sel = 0x07060504u - sh * 0x01010101u;
+                        uint32_t prev = 0;
+#pragma unroll
+                        for (int k = 0; k <= NR; k++) {
+                            const uint32_t cur = (k < NR) ? R[k < NR ? k : 0] : 0u;
+                            const uint32_t v = __builtin_amdgcn_perm(cur, prev, sel);
+                            prev = cur;
+                            if (v != 0u) atomicOr(tp + k + ((uint32_t)k >= kc ? 1 : 0), v);
+                        }
+                        oi[s] = oe[s];
                     }
                 }
                 any |= oi[s] < ce[s];
@@ -639,16 +681,22 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
             const uint32_t nunits = (full + 15u) >> 4;
             for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
                 const uint32_t lo = u << 4;
+                uint32_t* src = &L.outbuf[(lo >> 2) + (lo >> 6)];  // a unit never straddles a pad
                 if (out_aligned && lo + 16u <= full) {
-                    const uint32_t* src = &L.outbuf[(lo >> 2) + (lo >> 6)];  // a unit never straddles a pad
                     *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
                 } else {
                     for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[opad(i)];
                 }
+                if constexpr (LdsT::PRIV > 0) src[0] = src[1] = src[2] = src[3] = 0;
             }
             const uint32_t tail = total - full;  // < 16
             uint8_t tv = 0;
-            if ((uint32_t)tid < tail) tv = ob[opad(full + tid)];
+            if ((uint32_t)tid < tail) {
+                tv = ob[opad(full + tid)];
+                if constexpr (LdsT::PRIV > 0) {
+                    if (full > 0u) ob[opad(full + tid)] = 0;
+                }
+            }
             __syncthreads();
             if ((uint32_t)tid < tail) ob[opad((uint32_t)tid)] = tv;
             gpos += full;
@@ -694,7 +742,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
         hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false>), dim3(K), dim3(DCZ_K4_W), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4_OC, 0, true>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes,
                            off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
     } else {
         hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false>), dim3(K), dim3(1024), 0, s, d_comp,
