@@ -30,6 +30,7 @@
 // 10-bit-table-then-HashMap path returns.  Bits past the end of the payload read as zero
 // (TableBasedHuffmanDecoder.java:204-208); a missing code is "Huffman decode error at position i" (:109-111).
 #include <cstdlib>
+#include <utility>
 
 #include "dcz_internal.h"
 
@@ -54,8 +55,9 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4_NS 1      // subsequences per thread, many-blocks kernel
 #endif
 #ifndef DCZ_K4_PRIV
-#define DCZ_K4_PRIV 64   // symbols a subsequence parks in REGISTERS during phase A (PRIV/4 VGPRs), so that phase B
-#endif                   // copies them into the tile instead of decoding again; 0 = off
+#define DCZ_K4_PRIV 48   // symbols a subsequence parks in REGISTERS during phase A (PRIV/4 VGPRs), so that phase B
+#endif                   // copies them into the tile instead of decoding again; 0 = off.  48 keeps the kernel at
+                         // 96 VGPRs = 5 waves/SIMD without spills (64: 4 waves or spills; measured 6.95 vs 7.75 ms)
 #ifndef DCZ_K4S_PRIV
 #define DCZ_K4S_PRIV 64
 #endif
@@ -64,6 +66,12 @@ constexpr int TB = DCZ_K4_TB;
 #endif
 #ifndef DCZ_K4S_OC
 #define DCZ_K4S_OC 32768 // few-blocks kernel (one 1024-thread workgroup per block owns the CU: use its LDS)
+#endif
+#ifndef DCZ_K4_EXECMASK
+#define DCZ_K4_EXECMASK 0  // phase-A parking loop: 0 = wave-uniform branches + predication (faster, measured), 1 = per-lane exits
+#endif
+#ifndef DCZ_K4_MINWAVES
+#define DCZ_K4_MINWAVES 5  // waves per SIMD the many-blocks kernel is compiled for (caps its VGPRs at 96)
 #endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
@@ -115,6 +123,21 @@ typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 __device__ __forceinline__ unsigned long long fetch64(uint32_t npos) {
     lds_cu32* p = (lds_cu32*)(uintptr_t)((npos >> 3) & ~3u);
     return (unsigned long long)p[0] | ((unsigned long long)p[1] << 32);
+}
+// next 32 stream bits at descending position npos: one v_alignbit over the dword pair that ends with the window's last bit
+// (q = npos + 1: the pair is {dword holding the window's first bit or the one above it, dword holding its last bit}
+// and the shift q & 31 is what v_alignbit takes from the low 5 bits of its operand)
+__device__ __forceinline__ uint32_t window_q(uint32_t q) {
+    lds_cu32* p = (lds_cu32*)(uintptr_t)((q >> 3) & ~3u);
+    return __builtin_amdgcn_alignbit(p[1], p[0], q);
+}
+// a - ((e >> 8) & 0xFF) in one VALU op (SDWA byte select)
+__device__ __forceinline__ uint32_t sub_byte1(uint32_t a, uint32_t e) {
+    uint32_t r;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+        : "=v"(r)
+        : "v"(a), "v"(e));
+    return r;
 }
 // byte offset into the u16 table of the TB-bit window at npos
 __device__ __forceinline__ uint32_t table_off(unsigned long long two, uint32_t npos) {
@@ -186,7 +209,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
 }
 
 template <int W, int NS, int OC, int PV, bool MULTI>
-__global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
+__global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
                                                const uint32_t* __restrict__ d_orig_size,
@@ -452,28 +475,64 @@ __global__ __launch_bounds__(W) void k4_decode(const uint8_t* __restrict__ comp,
 #pragma unroll
                         for (int j = 0; j < NR; j++) R[j] = 0;
                     }
-#pragma unroll
-                    for (int k = 0; k < LdsT::PRIV; k++) {
-                        const bool a = np[0] > nl[0];
-                        if (__builtin_amdgcn_ballot_w64(a) == 0ull) break;
-                        const unsigned long long two = fetch64(np[0]);
-                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
-                                                                                                   table_off(two, np[0]));
-                        if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
-                            if (a && e == 0) {
-                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                    // One step per parked symbol (unrolled by hand so that symbol k lands in a compile-time
+                    // register); false ends the fold below.  q, ql: position and limit raised by 1, the form
+                    // window_q() wants.
+                    uint32_t q = np[0] + 1u, ql = (nl[0] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[0] + 1u;
+#if DCZ_K4_EXECMASK
+                    auto step = [&](auto kc) -> bool {  // per-lane exit: finished lanes are masked off
+                        constexpr int k = decltype(kc)::value;
+                        if (!(q > ql)) return false;
+                        const uint32_t w = window_q(q);
+                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + ((w >> (31 - TB)) & (uint32_t)(((1 << TB) - 1) << 1)));
+                        if (e == 0) {
+                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, w);
+                            if (e == 0) {
+                                bad[0] = true;
+                                ql = 0xFFFFFFFFu;
+                                return false;
+                            }
+                        }
+                        constexpr uint32_t sel = (k & 3) == 0 ? 0x03020104u : (k & 3) == 1 ? 0x03020400u : (k & 3) == 2 ? 0x03040100u : 0x04020100u;
+                        R[k >> 2] = __builtin_amdgcn_perm(e, R[k >> 2], sel);  // byte k&3 := symbol
+                        q = sub_byte1(q, e);  // q -= e >> 8 (e < 2^16)
+                        nsym[0]++;
+                        return true;
+                    };
+#else
+                    // wave-uniform control flow, per-lane predication: a lane that does not decode (any more) inserts
+                    // nothing (identity selector for lanes that keep their registers, a zero byte past the end of
+                    // the others) and moves by zero bits
+                    const uint32_t selv[4] = {need[0] ? 0x03020104u : 0x03020100u, need[0] ? 0x03020400u : 0x03020100u,
+                                              need[0] ? 0x03040100u : 0x03020100u, need[0] ? 0x04020100u : 0x03020100u};
+                    auto step = [&](auto kc) -> bool {
+                        constexpr int k = decltype(kc)::value;
+                        const unsigned long long am = __builtin_amdgcn_ballot_w64(q > ql);
+                        if (am == 0ull) return false;
+                        const uint32_t w = window_q(q);
+                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + ((w >> (31 - TB)) & (uint32_t)(((1 << TB) - 1) << 1)));
+                        if ((__builtin_amdgcn_ballot_w64(e == 0) & am) != 0ull) {
+                            if (q > ql && e == 0) {
+                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, w);
                                 if (e == 0) {
                                     bad[0] = true;
-                                    nl[0] = 0xFFFFFFFFu;
+                                    ql = 0xFFFFFFFFu;
                                 }
                             }
                         }
-                        const bool a2 = np[0] > nl[0];
+                        const bool a2 = q > ql;
                         e = a2 ? e : 0u;
-                        R[k >> 2] |= (e & 0xFFu) << (8 * (k & 3));
-                        np[0] -= e >> 8;
+                        R[k >> 2] = __builtin_amdgcn_perm(e, R[k >> 2], selv[k & 3]);
+                        q = sub_byte1(q, e);
                         nsym[0] += a2 ? 1u : 0u;
-                    }
+                        return true;
+                    };
+#endif
+                    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                        (void)(step(std::integral_constant<int, Is>{}) && ...);
+                    }(std::make_integer_sequence<int, LdsT::PRIV>{});
+                    np[0] = q - 1u;
+                    nl[0] = (ql == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql - 1u;
                     any = np[0] > nl[0];
                 }
             }
