@@ -67,9 +67,6 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4S_OC
 #define DCZ_K4S_OC 32768 // few-blocks kernel (one 1024-thread workgroup per block owns the CU: use its LDS)
 #endif
-#ifndef DCZ_K4_EXECMASK
-#define DCZ_K4_EXECMASK 0  // phase-A parking loop: 0 = wave-uniform branches + predication (faster, measured), 1 = per-lane exits
-#endif
 #ifndef DCZ_K4_MINWAVES
 #define DCZ_K4_MINWAVES 5  // waves per SIMD the many-blocks kernel is compiled for (caps its VGPRs at 96)
 #endif
@@ -96,6 +93,7 @@ struct DecLds {
     static constexpr int PRIV = (NS == 1) ? PV : 0;
     static_assert(PRIV % 4 == 0, "whole registers");
     uint32_t cend_vote;
+    uint32_t flag[3];
     uint16_t table[1 << TB];
     // short-code kernel (MULTI): per TB-bit window, the maximal run of complete codewords inside it
     //   mcount: (symbols << 4) | bits                      -> phase A skips several symbols per lookup
@@ -419,6 +417,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                 if (beyond[s]) need[s] = false;
             }
         }
+        uint32_t round = 0;
         while (true) {
             // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
             // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are
@@ -479,60 +478,42 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                     // register); false ends the fold below.  q, ql: position and limit raised by 1, the form
                     // window_q() wants.
                     uint32_t q = np[0] + 1u, ql = (nl[0] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[0] + 1u;
-#if DCZ_K4_EXECMASK
-                    auto step = [&](auto kc) -> bool {  // per-lane exit: finished lanes are masked off
-                        constexpr int k = decltype(kc)::value;
-                        if (!(q > ql)) return false;
-                        const uint32_t w = window_q(q);
-                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + ((w >> (31 - TB)) & (uint32_t)(((1 << TB) - 1) << 1)));
-                        if (e == 0) {
-                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, w);
-                            if (e == 0) {
-                                bad[0] = true;
-                                ql = 0xFFFFFFFFu;
-                                return false;
-                            }
-                        }
-                        constexpr uint32_t sel = (k & 3) == 0 ? 0x03020104u : (k & 3) == 1 ? 0x03020400u : (k & 3) == 2 ? 0x03040100u : 0x04020100u;
-                        R[k >> 2] = __builtin_amdgcn_perm(e, R[k >> 2], sel);  // byte k&3 := symbol
-                        q = sub_byte1(q, e);  // q -= e >> 8 (e < 2^16)
-                        nsym[0]++;
-                        return true;
-                    };
-#else
-                    // wave-uniform control flow, per-lane predication: a lane that does not decode (any more) inserts
+                    // Wave-uniform control flow, per-lane predication: a lane that does not decode (any more) inserts
                     // nothing (identity selector for lanes that keep their registers, a zero byte past the end of
-                    // the others) and moves by zero bits
+                    // the others) and moves by zero bits.
+                    // q20 = q + 20: the 32 bits that END 12 bits past the position, so the TB-bit table index sits at
+                    // bits [TB:1] of the aligned pair and one v_and yields the byte offset of the u16 entry.
+                    static_assert(TB == 11, "index position in the early window");
                     const uint32_t selv[4] = {need[0] ? 0x03020104u : 0x03020100u, need[0] ? 0x03020400u : 0x03020100u,
                                               need[0] ? 0x03040100u : 0x03020100u, need[0] ? 0x04020100u : 0x03020100u};
-                    auto step = [&](auto kc) -> bool {
+                    uint32_t q20 = q + 20u, ql20 = (ql == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql + 20u;
+                    auto step = [&](auto kc) __attribute__((always_inline)) -> bool {
                         constexpr int k = decltype(kc)::value;
-                        const unsigned long long am = __builtin_amdgcn_ballot_w64(q > ql);
+                        bool a = q20 > ql20;
+                        const unsigned long long am = __builtin_amdgcn_ballot_w64(a);
                         if (am == 0ull) return false;
-                        const uint32_t w = window_q(q);
-                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + ((w >> (31 - TB)) & (uint32_t)(((1 << TB) - 1) << 1)));
-                        if ((__builtin_amdgcn_ballot_w64(e == 0) & am) != 0ull) {
-                            if (q > ql && e == 0) {
-                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, w);
+                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + (window_q(q20) & (uint32_t)(((1 << TB) - 1) << 1)));
+                        if ((__builtin_amdgcn_ballot_w64(e == 0) & am) != 0ull) {  // rare: long codeword or no codeword
+                            if (a && e == 0) {
+                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, window_q(q20 - 20u));
                                 if (e == 0) {
                                     bad[0] = true;
-                                    ql = 0xFFFFFFFFu;
+                                    ql20 = 0xFFFFFFFFu;
+                                    a = false;
                                 }
                             }
                         }
-                        const bool a2 = q > ql;
-                        e = a2 ? e : 0u;
+                        e = a ? e : 0u;
                         R[k >> 2] = __builtin_amdgcn_perm(e, R[k >> 2], selv[k & 3]);
-                        q = sub_byte1(q, e);
-                        nsym[0] += a2 ? 1u : 0u;
+                        q20 = sub_byte1(q20, e);
+                        nsym[0] += a ? 1u : 0u;
                         return true;
                     };
-#endif
                     [&]<int... Is>(std::integer_sequence<int, Is...>) {
                         (void)(step(std::integral_constant<int, Is>{}) && ...);
                     }(std::make_integer_sequence<int, LdsT::PRIV>{});
-                    np[0] = q - 1u;
-                    nl[0] = (ql == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql - 1u;
+                    np[0] = q20 - 21u;
+                    nl[0] = (ql20 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql20 - 21u;
                     any = np[0] > nl[0];
                 }
             }
@@ -573,7 +554,13 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                 if (need[s]) x[s] = bad[s] ? 0u : (nbase - np[s]) - (uint32_t)(s + 1) * SUB_BITS;
 #pragma unroll
             for (int s = 0; s < NS; s++) L.exits[q0 + s] = (uint16_t)x[s];
+            // One barrier per round.  Whether anybody had to decode in THIS round was recorded in flag[round % 3]
+            // during the previous round's check; it becomes visible with this round's barrier.  If nobody had to,
+            // every exit is unchanged and the entries are final.  (Slot (round + 1) % 3 is cleared before the
+            // barrier, set after it and read after the next one.)
+            if (tid == 0) L.flag[(round + 1u) % 3u] = 0;
             __syncthreads();
+            if (round > 0u && L.flag[round % 3u] == 0u) break;
             bool anyneed = false;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
@@ -583,7 +570,8 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                 g[s] = ng;
                 anyneed |= need[s];
             }
-            if (!__syncthreads_or(anyneed)) break;
+            if (__builtin_amdgcn_ballot_w64(anyneed) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
+            round++;
         }
 
         // ---- offsets, errors ----
@@ -670,7 +658,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                             const uint32_t cur = (k < NR) ? R[k < NR ? k : 0] : 0u;
                             const uint32_t v = __builtin_amdgcn_perm(cur, prev, sel);
                             prev = cur;
-                            if (v != 0u) atomicOr(tp + k + ((uint32_t)k >= kc ? 1 : 0), v);
+                            atomicOr(tp + k + ((uint32_t)k >= kc ? 1 : 0), v);  // OR-ing zero is a no-op: no guard
                         }
                         oi[s] = oe[s];
                     }
