@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, N
     return base + inc - v;
 }
 
-// Load one 16-byte chunk of the payload (virtual byte vb), zero outside [vlo, vhi), MSB-first dwords.
+// Load one 16-byte chunk of the payload (virtual byte vb), zero outside [vlo, vhi).
 __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long long vb, unsigned long long vlo,
                                             unsigned long long vhi) {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -203,8 +203,22 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
             v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
     }
-    return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+    return v;  // little-endian as loaded: the byte swap to MSB-first dwords happens when the registers are staged,
+               // so that nothing waits for the load where it is issued
 }
+
+#if DCZ_K4_PROF
+// debug build only: cycles per phase, summed over wave 0 of every workgroup (tools/k4prof.py)
+__device__ unsigned long long k4_prof[8];
+#define PROF_T(i)                                         \
+    do {                                                  \
+        const unsigned long long t_ = clock64();          \
+        pacc[i] += t_ - plast;                            \
+        plast = t_;                                       \
+    } while (0)
+#else
+#define PROF_T(i) do { } while (0)
+#endif
 
 template <int W, int NS, int OC, int PV, bool MULTI>
 __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
@@ -364,6 +378,10 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
     };
     if (orig > 0) prefetch(ventry >> 7);
 
+#if DCZ_K4_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = clock64();
+#endif
     while (produced < orig) {
         const unsigned long long wchunk0 = ventry >> 7;
         const uint32_t g0 = (uint32_t)(ventry - (wchunk0 << 7));
@@ -372,6 +390,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
         // end of the previous stripe as its look-ahead
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+            pre[c] = make_uint4(bswap32(pre[c].x), bswap32(pre[c].y), bswap32(pre[c].z), bswap32(pre[c].w));
             cb[LdsT::STRIPE + 1 - (4 * c + 0)] = pre[c].x;
             cb[LdsT::STRIPE + 1 - (4 * c + 1)] = pre[c].y;
             cb[LdsT::STRIPE + 1 - (4 * c + 2)] = pre[c].z;
@@ -382,10 +401,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
             cb[0 - LdsT::STRIDE] = pre[0].y;  // previous stripe, logical dword STRIPE + 1
         }
         if (tid == W - 1) {
-            cb[1] = pre_m.x;
-            cb[0] = pre_m.y;
+            cb[1] = bswap32(pre_m.x);
+            cb[0] = bswap32(pre_m.y);
         }
         __syncthreads();
+        PROF_T(1);
 
         // ---- phase A: self-synchronisation (positions are stripe-local bit offsets) ----
         uint32_t g[NS], x[NS], nsym[NS];
@@ -549,6 +569,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                     any |= np[s] > nl[s];
                 }
             }
+            PROF_T(0);
 #pragma unroll
             for (int s = 0; s < NS; s++)  // final pos >= limit (or the start itself when it lies past the limit)
                 if (need[s]) x[s] = bad[s] ? 0u : (nbase - np[s]) - (uint32_t)(s + 1) * SUB_BITS;
@@ -560,6 +581,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
             // barrier, set after it and read after the next one.)
             if (tid == 0) L.flag[(round + 1u) % 3u] = 0;
             __syncthreads();
+            PROF_T(2);
             if (round > 0u && L.flag[round % 3u] == 0u) break;
             bool anyneed = false;
 #pragma unroll
@@ -592,6 +614,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
         const unsigned long long next_ventry =
             (wchunk0 << 7) + (unsigned long long)LdsT::NSUB * SUB_BITS + (unsigned long long)L.exits[LdsT::NSUB - 1];
         __syncthreads();
+        PROF_T(3);
         const uint32_t err_idx = L.err_idx;
         if (err_idx < remaining) {
             status = DCZ_E_BADSTREAM;
@@ -601,6 +624,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
         const uint32_t lim = (tw < remaining) ? tw : remaining;
         const bool more = produced + lim < orig;
         if (more) prefetch(next_ventry >> 7);  // lands in registers while phase B runs
+        PROF_T(4);
 
         // ---- phase B: decode into the staging tile, flush aligned 16-byte units ----
         // per stream: np = descending bit position, oi = window symbol index of its next symbol, oe = one past its
@@ -721,6 +745,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                 }
             }
             __syncthreads();
+            PROF_T(5);
             const uint32_t total = ocarry + cc;
             const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
             const uint32_t full = last ? total : (total & ~15u);
@@ -745,6 +770,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                 }
             }
             __syncthreads();
+            PROF_T(6);
             if ((uint32_t)tid < tail) ob[opad((uint32_t)tid)] = tv;
             gpos += full;
             ocarry = tail;
@@ -766,11 +792,15 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
             break;
         }
         __syncthreads();
+        PROF_T(7);
     }
 
     if (tid == 0) {
         d_status[b] = status;
         if (d_errpos) d_errpos[b] = errpos;
+#if DCZ_K4_PROF
+        for (int i = 0; i < 8; i++) atomicAdd(&k4_prof[i], pacc[i]);
+#endif
     }
 }
 
@@ -800,3 +830,13 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 }
 
 }  // namespace dcz
+
+#if DCZ_K4_PROF
+extern "C" void dcz_debug_k4_prof(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::k4_prof), sizeof(dcz::k4_prof));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(dcz::k4_prof), z, sizeof(z));
+    }
+}
+#endif
