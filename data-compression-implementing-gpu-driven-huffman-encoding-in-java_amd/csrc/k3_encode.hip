@@ -11,11 +11,11 @@
 // Design.  One WAVE owns one 32 KiB segment of a block; its first bit offset comes from K2
 // (d_seg_bitoff), so waves never wait for each other and there is no inter-workgroup traffic.
 //   * input: 16 B/lane coalesced loads (1 KiB per wave instruction), next chunk prefetched;
-//   * codebook: LDS, 256 entries of code<<6|len, replicated K3_COPIES times across the banks (entry s of
+//   * codebook: LDS, 256 entries of code<<16|len (code<<6|len when maxlen>16), replicated K3_COPIES times across the banks (entry s of
 //     replica r at dword s*COPIES+r, lane l reads replica l % COPIES) so that lookups of equal or different
 //     symbols by different lanes rarely collide, whatever the data;
-//   * each lane concatenates G consecutive codewords in registers (G=4 when maxlen<=16, G=2 when
-//     maxlen<=26; a wide path with 64-bit entries covers maxlen<=32), a DPP wave scan of the lane
+//   * each lane concatenates G consecutive codewords in registers (G=8 when maxlen<=8, G=4 when maxlen<=16,
+//     G=2 when maxlen<=26; a wide path with 64-bit entries covers maxlen<=32), a DPP wave scan of the lane
 //     bit counts gives every lane its bit offset (no LDS, no ballot needed);
 //   * lanes OR their strings into a per-wave 4 KiB LDS ring (ds_or_b32), indexed by stream position
 //     relative to a 16-byte-aligned origin of the OUTPUT address, so that complete 16-byte chunks
@@ -117,31 +117,72 @@ __device__ __forceinline__ uint4 load_lane16(const uint8_t* p, int nb, bool fast
     return v;
 }
 
-// Packed 32-bit entries (code << 6 | len), G symbols per register string.
-template <int G>
+// Packed 32-bit entries, G symbols per register string; FULL = every lane holds 16 valid bytes.
+//   G == 2 (maxlen <= 26): entry = code << 6 | len, strings built by 64-bit shifts;
+//   G == 4 (maxlen <= 16), G == 8 (maxlen <= 8): entry = code << 16 | len; adjacent codewords are first joined
+//   in 32-bit registers (a pair is <= 32 bits, and for maxlen <= 8 so is a quad), then once in 64 bits.
+template <int G, bool FULL>
 __device__ __forceinline__ void encode_chunk_packed(EncState& st, const uint32_t* lut, uint32_t col, const uint4& d,
                                                     int nb, int lane) {
     const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
     unsigned long long gs[16 / G];
     uint32_t gl[16 / G];
     uint32_t total = 0;
+    if constexpr (G == 2) {
 #pragma unroll
-    for (int q = 0; q < 16 / G; q++) {
-        unsigned long long g = 0;
-        uint32_t l = 0;
+        for (int q = 0; q < 16 / G; q++) {
+            unsigned long long g = 0;
+            uint32_t l = 0;
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const int i = q * G + k;
-            const uint32_t sym = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            uint32_t e = lut[(sym << K3_CSHIFT) + col];
-            if (i >= nb) e = 0;
-            const uint32_t li = e & 63u;
-            g = (g << li) | (unsigned long long)(e >> 6);
-            l += li;
+            for (int k = 0; k < G; k++) {
+                const int i = q * G + k;
+                const uint32_t sym = (dw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                uint32_t e = lut[(sym << K3_CSHIFT) + col];
+                if (!FULL && i >= nb) e = 0;
+                const uint32_t li = e & 63u;
+                g = (g << li) | (unsigned long long)(e >> 6);
+                l += li;
+            }
+            gs[q] = g;
+            gl[q] = l;
+            total += l;
         }
-        gs[q] = g;
-        gl[q] = l;
-        total += l;
+    } else {
+        uint32_t pc[8], pl[8];  // pairs
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i0 = 2 * j, i1 = 2 * j + 1;
+            const uint32_t s0 = (dw[i0 >> 2] >> (8 * (i0 & 3))) & 0xFFu;
+            const uint32_t s1 = (dw[i1 >> 2] >> (8 * (i1 & 3))) & 0xFFu;
+            uint32_t e0 = lut[(s0 << K3_CSHIFT) + col];
+            uint32_t e1 = lut[(s1 << K3_CSHIFT) + col];
+            if (!FULL && i0 >= nb) e0 = 0;
+            if (!FULL && i1 >= nb) e1 = 0;
+            const uint32_t l1 = e1 & 0xFFu;
+            pc[j] = ((e0 >> 16) << l1) | (e1 >> 16);
+            pl[j] = (e0 & 0xFFu) + l1;
+        }
+        if constexpr (G == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                gs[q] = ((unsigned long long)pc[2 * q] << pl[2 * q + 1]) | (unsigned long long)pc[2 * q + 1];
+                gl[q] = pl[2 * q] + pl[2 * q + 1];
+                total += gl[q];
+            }
+        } else {
+            uint32_t qc[4], ql[4];  // quads still fit 32 bits
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                qc[q] = (pc[2 * q] << pl[2 * q + 1]) | pc[2 * q + 1];
+                ql[q] = pl[2 * q] + pl[2 * q + 1];
+            }
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                gs[o] = ((unsigned long long)qc[2 * o] << ql[2 * o + 1]) | (unsigned long long)qc[2 * o + 1];
+                gl[o] = ql[2 * o] + ql[2 * o + 1];
+                total += gl[o];
+            }
+        }
     }
     const uint32_t inc = wave_inclusive_scan_u32(total);
     const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -209,7 +250,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     if (!wide) {
         for (int i = tid; i < 256 * K3_COPIES; i += K3_WAVES * 64) {
             const int s = i >> K3_CSHIFT;
-            lut[i] = (d_code[(uint64_t)b * 256u + s] << 6) | (uint32_t)d_len[(uint64_t)b * 256u + s];
+            const uint32_t cd = d_code[(uint64_t)b * 256u + s], ln = d_len[(uint64_t)b * 256u + s];
+            lut[i] = (maxlen <= 16) ? ((cd << 16) | ln) : ((cd << 6) | ln);
         }
     } else {
         for (int s = tid; s < 256; s += K3_WAVES * 64)
@@ -267,10 +309,17 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                 nxt = load_lane16(src + o, (int)slen - (int)o, fast);
             }
             const int nb = (int)slen - (int)(c * 1024u) - lane * 16;
-            if (maxlen <= 16)
-                encode_chunk_packed<4>(st, lut, col, cur, nb, lane);
-            else
-                encode_chunk_packed<2>(st, lut, col, cur, nb, lane);
+            const bool full = slen - c * 1024u >= 1024u;  // wave-uniform
+            if (maxlen <= 8) {
+                if (full) encode_chunk_packed<8, true>(st, lut, col, cur, nb, lane);
+                else encode_chunk_packed<8, false>(st, lut, col, cur, nb, lane);
+            } else if (maxlen <= 16) {
+                if (full) encode_chunk_packed<4, true>(st, lut, col, cur, nb, lane);
+                else encode_chunk_packed<4, false>(st, lut, col, cur, nb, lane);
+            } else {
+                if (full) encode_chunk_packed<2, true>(st, lut, col, cur, nb, lane);
+                else encode_chunk_packed<2, false>(st, lut, col, cur, nb, lane);
+            }
             if (c == 0 && clear_chunk0) {
                 wave_lds_fence();
                 if (lane < 4) st.ring[lane] = 0u;
