@@ -90,7 +90,7 @@ struct DecLds {
     // Phase A parks the first PRIV symbols of each subsequence in registers; after the fixed point the LAST decode
     // of a subsequence started at its true entry, so phase B ORs them into the (zeroed) tile as whole dwords
     // instead of decoding again.
-    static constexpr int PRIV = (NS == 1) ? PV : 0;
+    static constexpr int PRIV = PV;
     static_assert(PRIV % 4 == 0, "whole registers");
     uint32_t cend_vote;
     uint32_t flag[3];
@@ -356,9 +356,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
     uint32_t* const cb = &L.cbuf[(uint32_t)tid * (uint32_t)LdsT::STRIDE];  // this thread's stripe (descending)
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.outbuf);
     constexpr int NR = LdsT::PRIV > 0 ? LdsT::PRIV / 4 : 1;
-    uint32_t R[NR];  // parked symbols, 4 per register, first symbol in the low byte
+    uint32_t R[NS][NR];  // parked symbols of each stream, 4 per register, first symbol in the low byte
 #pragma unroll
-    for (int j = 0; j < NR; j++) R[j] = 0;
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int j = 0; j < NR; j++) R[s][j] = 0;
     // descending-position origin: logical dword j of the stripe lives at cb[STRIPE + 1 - j]
     const uint32_t top_addr =
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
@@ -488,53 +490,75 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
             }
             if constexpr (LdsT::PRIV > 0) {
                 if (park) {  // workgroup-uniform
-                    // Fully unrolled so that symbol k lands in a compile-time register; leaves (wave-uniformly) as
-                    // soon as no lane is active.  Lanes that do not decode this round keep their registers.
-                    if (need[0]) {
-#pragma unroll
-                        for (int j = 0; j < NR; j++) R[j] = 0;
-                    }
-                    // One step per parked symbol (unrolled by hand so that symbol k lands in a compile-time
-                    // register); false ends the fold below.  q, ql: position and limit raised by 1, the form
-                    // window_q() wants.
-                    uint32_t q = np[0] + 1u, ql = (nl[0] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[0] + 1u;
-                    // Wave-uniform control flow, per-lane predication: a lane that does not decode (any more) inserts
-                    // nothing (identity selector for lanes that keep their registers, a zero byte past the end of
-                    // the others) and moves by zero bits.
-                    // q20 = q + 20: the 32 bits that END 12 bits past the position, so the TB-bit table index sits at
-                    // bits [TB:1] of the aligned pair and one v_and yields the byte offset of the u16 entry.
+                    // Hand-unrolled: symbol k of every stream lands in a compile-time register; the fold leaves
+                    // (wave-uniformly) as soon as no lane has an active stream.  Per-lane predication: a stream that
+                    // does not decode (any more) inserts nothing (identity selector when it keeps its registers from
+                    // an earlier round, a zero byte past its end otherwise) and moves by zero bits.
+                    // q20 = descending position + 21: window_q(q20) is the 32 bits that END 12 bits past the
+                    // position, so the TB-bit table index sits at bits [TB:1] of the aligned pair and one v_and
+                    // yields the byte offset of the u16 entry.
                     static_assert(TB == 11, "index position in the early window");
-                    const uint32_t selv[4] = {need[0] ? 0x03020104u : 0x03020100u, need[0] ? 0x03020400u : 0x03020100u,
-                                              need[0] ? 0x03040100u : 0x03020100u, need[0] ? 0x04020100u : 0x03020100u};
-                    uint32_t q20 = q + 20u, ql20 = (ql == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql + 20u;
+                    uint32_t q20[NS], ql20[NS], selv[NS][4];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) {
+                        if (need[s]) {
+#pragma unroll
+                            for (int j = 0; j < NR; j++) R[s][j] = 0;
+                        }
+                        q20[s] = np[s] + 21u;
+                        ql20[s] = (nl[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[s] + 21u;
+                        selv[s][0] = need[s] ? 0x03020104u : 0x03020100u;
+                        selv[s][1] = need[s] ? 0x03020400u : 0x03020100u;
+                        selv[s][2] = need[s] ? 0x03040100u : 0x03020100u;
+                        selv[s][3] = need[s] ? 0x04020100u : 0x03020100u;
+                    }
                     auto step = [&](auto kc) __attribute__((always_inline)) -> bool {
                         constexpr int k = decltype(kc)::value;
-                        bool a = q20 > ql20;
-                        const unsigned long long am = __builtin_amdgcn_ballot_w64(a);
-                        if (am == 0ull) return false;
-                        uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + (window_q(q20) & (uint32_t)(((1 << TB) - 1) << 1)));
-                        if ((__builtin_amdgcn_ballot_w64(e == 0) & am) != 0ull) {  // rare: long codeword or no codeword
-                            if (a && e == 0) {
-                                e = slow_lookup<W, NS, OC, PV, MULTI>(L, window_q(q20 - 20u));
-                                if (e == 0) {
-                                    bad[0] = true;
-                                    ql20 = 0xFFFFFFFFu;
-                                    a = false;
-                                }
-                            }
+                        bool a[NS], anya = false;
+#pragma unroll
+                        for (int s = 0; s < NS; s++) {
+                            a[s] = q20[s] > ql20[s];
+                            anya |= a[s];
                         }
-                        e = a ? e : 0u;
-                        R[k >> 2] = __builtin_amdgcn_perm(e, R[k >> 2], selv[k & 3]);
-                        q20 = sub_byte1(q20, e);
-                        nsym[0] += a ? 1u : 0u;
+                        if (__builtin_amdgcn_ballot_w64(anya) == 0ull) return false;
+                        uint32_t e[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                            e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + (window_q(q20[s]) & (uint32_t)(((1 << TB) - 1) << 1)));
+                        bool miss = false;
+#pragma unroll
+                        for (int s = 0; s < NS; s++) miss |= a[s] && e[s] == 0;
+                        if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {  // rare: long codeword or no codeword
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                                if (a[s] && e[s] == 0) {
+                                    e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window_q(q20[s] - 20u));
+                                    if (e[s] == 0) {
+                                        bad[s] = true;
+                                        ql20[s] = 0xFFFFFFFFu;
+                                        a[s] = false;
+                                    }
+                                }
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; s++) {
+                            e[s] = a[s] ? e[s] : 0u;
+                            R[s][k >> 2] = __builtin_amdgcn_perm(e[s], R[s][k >> 2], selv[s][k & 3]);
+                            q20[s] = sub_byte1(q20[s], e[s]);
+                            nsym[s] += a[s] ? 1u : 0u;
+                        }
                         return true;
                     };
                     [&]<int... Is>(std::integer_sequence<int, Is...>) {
                         (void)(step(std::integral_constant<int, Is>{}) && ...);
                     }(std::make_integer_sequence<int, LdsT::PRIV>{});
-                    np[0] = q20 - 21u;
-                    nl[0] = (ql20 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql20 - 21u;
-                    any = np[0] > nl[0];
+                    any = false;
+#pragma unroll
+                    for (int s = 0; s < NS; s++) {
+                        np[s] = q20[s] - 21u;
+                        nl[s] = (ql20[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql20[s] - 21u;
+                        any |= np[s] > nl[s];
+                    }
                 }
             }
             while (!MULTI && any) {
@@ -629,13 +653,14 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
         // ---- phase B: decode into the staging tile, flush aligned 16-byte units ----
         // per stream: np = descending bit position, oi = window symbol index of its next symbol, oe = one past its
         // last symbol inside the block
-        uint32_t np[NS], oi[NS], oe[NS];
+        uint32_t np[NS], oi[NS], oe[NS], os[NS];  // os = window symbol index of the stream's first symbol
         {
             uint32_t oo = o;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const uint32_t end = oo + nsym[s];
                 oi[s] = oo;
+                os[s] = oo;
                 oe[s] = end < lim ? end : lim;
                 if (oe[s] < oi[s]) oe[s] = oi[s];
                 np[s] = nbase - ((nsym[s] > 0) ? (uint32_t)s * SUB_BITS + g[s] : 0u);
@@ -651,8 +676,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                     if (park) {  // end the flush on a subsequence boundary: no parked run straddles it
                         if (tid == 0) L.cend_vote = 0;
                         __syncthreads();
-                        const uint32_t end0 = o + nsym[0];
-                        if (end0 > cbase + room / 2u && end0 <= cbase + room) atomicMax(&L.cend_vote, end0);
+#pragma unroll
+                        for (int s = 0; s < NS; s++) {
+                            const uint32_t end0 = os[s] + nsym[s];
+                            if (end0 > cbase + room / 2u && end0 <= cbase + room) atomicMax(&L.cend_vote, end0);
+                        }
                         __syncthreads();
                         const uint32_t v = L.cend_vote;
                         if (v != 0u) cc = v - cbase;
@@ -670,7 +698,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                     static_assert(LdsT::PRIV <= 64, "a parked run crosses at most one tile pad");
                     // a wholly parked subsequence that lies inside this flush: OR its registers into the tile,
                     // shifted to the byte phase of its first symbol (bytes outside the run are zero)
-                    if (park && nsym[s] <= (uint32_t)LdsT::PRIV && oi[s] == o && oi[s] < oe[s] && oe[s] <= cend) {
+                    if (park && nsym[s] <= (uint32_t)LdsT::PRIV && oi[s] == os[s] && oi[s] < oe[s] && oe[s] <= cend) {
                         const uint32_t d = oi[s] + tshift;  // logical tile byte of the first symbol
                         const uint32_t sh = d & 3u, dw = d >> 2;
                         uint32_t* const tp = &L.outbuf[dw + (dw >> 4)];
@@ -679,7 +707,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                         uint32_t prev = 0;
 #pragma unroll
                         for (int k = 0; k <= NR; k++) {
-                            const uint32_t cur = (k < NR) ? R[k < NR ? k : 0] : 0u;
+                            const uint32_t cur = (k < NR) ? R[s][k < NR ? k : 0] : 0u;
                             const uint32_t v = __builtin_amdgcn_perm(cur, prev, sel);
                             prev = cur;
                             atomicOr(tp + k + ((uint32_t)k >= kc ? 1 : 0), v);  // OR-ing zero is a no-op: no guard
