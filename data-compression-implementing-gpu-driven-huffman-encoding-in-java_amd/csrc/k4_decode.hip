@@ -70,6 +70,9 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4_MINWAVES
 #define DCZ_K4_MINWAVES 5  // waves per SIMD the many-blocks kernel is compiled for (caps its VGPRs at 96)
 #endif
+#ifndef DCZ_K4_OUTLINE_SLOW
+#define DCZ_K4_OUTLINE_SLOW 1  // parking loop calls the long-code search instead of inlining it in every step
+#endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
 #endif
@@ -137,6 +140,17 @@ __device__ __forceinline__ uint32_t sub_byte1(uint32_t a, uint32_t e) {
         : "v"(a), "v"(e));
     return r;
 }
+// lane in mask ? v : 0, and n + (lane in mask), with the wave mask in a scalar register pair
+__device__ __forceinline__ uint32_t select_mask(uint32_t v, unsigned long long m) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_mask(uint32_t n, unsigned long long m) {
+    uint32_t r;
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(n), "s"(m) : "vcc");
+    return r;
+}
 // byte offset into the u16 table of the TB-bit window at npos
 __device__ __forceinline__ uint32_t table_off(unsigned long long two, uint32_t npos) {
     return (uint32_t)(two >> ((npos & 31u) + (uint32_t)(32 - TB))) & (uint32_t)(((1 << TB) - 1) << 1);
@@ -160,6 +174,28 @@ __device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV, MULT
         if (k < 4u) {
             const uint32_t ll = l + k;  // <= maxlen: lim[] is flat beyond maxlen, so a later length never wins
             return (ll << 8) | (uint32_t)L.symtab[L.offs[ll] + ((win32 >> (32u - ll)) - L.first[ll])];
+        }
+    }
+    return 0;
+}
+
+// The same search as an out-of-line function on LDS addresses: the hand-unrolled parking loop would otherwise carry
+// one inlined copy per step and outgrow the instruction cache.
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __attribute__((noinline)) uint32_t slow_lookup_outlined(uint32_t lim_a, uint32_t first_a, uint32_t offs_a,
+                                                                   uint32_t symtab_a, uint32_t maxlen, uint32_t win32) {
+    lds_cu64* lim = (lds_cu64*)(uintptr_t)lim_a;
+    lds_cu32* first = (lds_cu32*)(uintptr_t)first_a;
+    lds_cu32* offs = (lds_cu32*)(uintptr_t)offs_a;
+    lds_cu8* symtab = (lds_cu8*)(uintptr_t)symtab_a;
+    const unsigned long long w = win32;
+    for (uint32_t l = TB + 1; l <= maxlen; l += 4) {
+        const unsigned long long a = lim[l], b = lim[l + 1], c = lim[l + 2], d = lim[l + 3];
+        const uint32_t k = (w < a) ? 0u : (w < b) ? 1u : (w < c) ? 2u : (w < d) ? 3u : 4u;
+        if (k < 4u) {
+            const uint32_t ll = l + k;
+            return (ll << 8) | (uint32_t)symtab[offs[ll] + ((win32 >> (32u - ll)) - first[ll])];
         }
     }
     return 0;
@@ -366,6 +402,10 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(cb + LdsT::STRIPE));
     const uint32_t nbase = 8u * top_addr + 31u;  // npos = nbase - pos
     const uint32_t tbl_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.table[0]));
+    const uint32_t lim_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned long long*)(&L.lim[0]));
+    const uint32_t first_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.first[0]));
+    const uint32_t offs_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.offs[0]));
+    const uint32_t symtab_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)(&L.symtab[0]));
     const uint32_t mcount_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.mcount[0]));
     const uint32_t mout_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.mout[0]));
 
@@ -512,40 +552,51 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                         selv[s][2] = need[s] ? 0x03040100u : 0x03020100u;
                         selv[s][3] = need[s] ? 0x04020100u : 0x03020100u;
                     }
+                    // Lane activity is kept as wave masks in scalar registers (am[s]); the per-lane selects and the
+                    // symbol count read them directly (v_cndmask / v_addc with a scalar mask operand).
                     auto step = [&](auto kc) __attribute__((always_inline)) -> bool {
                         constexpr int k = decltype(kc)::value;
-                        bool a[NS], anya = false;
+                        unsigned long long am[NS], any_m = 0;
 #pragma unroll
                         for (int s = 0; s < NS; s++) {
-                            a[s] = q20[s] > ql20[s];
-                            anya |= a[s];
+                            am[s] = __builtin_amdgcn_ballot_w64(q20[s] > ql20[s]);
+                            any_m |= am[s];
                         }
-                        if (__builtin_amdgcn_ballot_w64(anya) == 0ull) return false;
+                        if (any_m == 0ull) return false;
                         uint32_t e[NS];
+                        unsigned long long miss_m = 0;
 #pragma unroll
-                        for (int s = 0; s < NS; s++)
+                        for (int s = 0; s < NS; s++) {
                             e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + (window_q(q20[s]) & (uint32_t)(((1 << TB) - 1) << 1)));
-                        bool miss = false;
+                            asm("" : "+v"(e[s]));  // a plain 32-bit value from here on (no 16-bit compare + re-extension)
+                            miss_m |= __builtin_amdgcn_ballot_w64(e[s] == 0u) & am[s];
+                        }
+                        if (miss_m != 0ull) {  // rare: long codeword or no codeword
 #pragma unroll
-                        for (int s = 0; s < NS; s++) miss |= a[s] && e[s] == 0;
-                        if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {  // rare: long codeword or no codeword
-#pragma unroll
-                            for (int s = 0; s < NS; s++)
-                                if (a[s] && e[s] == 0) {
+                            for (int s = 0; s < NS; s++) {
+                                bool dead = false;
+                                if (q20[s] > ql20[s] && e[s] == 0u) {
+#if DCZ_K4_OUTLINE_SLOW
+                                    e[s] = slow_lookup_outlined(lim_addr, first_addr, offs_addr, symtab_addr, L.maxlen,
+                                                                window_q(q20[s] - 20u));
+#else
                                     e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window_q(q20[s] - 20u));
-                                    if (e[s] == 0) {
+#endif
+                                    if (e[s] == 0u) {
                                         bad[s] = true;
                                         ql20[s] = 0xFFFFFFFFu;
-                                        a[s] = false;
+                                        dead = true;
                                     }
                                 }
+                                am[s] &= ~__builtin_amdgcn_ballot_w64(dead);
+                            }
                         }
 #pragma unroll
                         for (int s = 0; s < NS; s++) {
-                            e[s] = a[s] ? e[s] : 0u;
+                            e[s] = select_mask(e[s], am[s]);
                             R[s][k >> 2] = __builtin_amdgcn_perm(e[s], R[s][k >> 2], selv[s][k & 3]);
                             q20[s] = sub_byte1(q20[s], e[s]);
-                            nsym[s] += a[s] ? 1u : 0u;
+                            nsym[s] = add_mask(nsym[s], am[s]);
                         }
                         return true;
                     };
