@@ -58,6 +58,9 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4_PRIV 48   // symbols a subsequence parks in REGISTERS during phase A (PRIV/4 VGPRs), so that phase B
 #endif                   // copies them into the tile instead of decoding again; 0 = off.  48 keeps the kernel at
                          // 96 VGPRs = 5 waves/SIMD without spills (64: 4 waves or spills; measured 6.95 vs 7.75 ms)
+#ifndef DCZ_K4_PRIVM
+#define DCZ_K4_PRIVM 96  // parking capacity of the instantiation for medium code lengths (3.6 .. 6.5 bits), 0 = none
+#endif
 #ifndef DCZ_K4S_PRIV
 #define DCZ_K4S_PRIV 64
 #endif
@@ -256,8 +259,11 @@ __device__ unsigned long long k4_prof[8];
 #define PROF_T(i) do { } while (0)
 #endif
 
-template <int W, int NS, int OC, int PV, bool MULTI>
-__global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
+// CMASK: the block classes this instantiation decodes (bit 2: >= 6.5 bits per symbol on average, bit 1: at most 72
+// symbols per 32-byte subsequence, bit 0: shorter codes); every launch covers all blocks and each workgroup leaves at
+// once unless its block is of a class it owns.
+template <int W, int NS, int OC, int PV, bool MULTI, int CMASK>
+__global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAVES : 4) : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
                                                const uint32_t* __restrict__ d_orig_size,
@@ -274,11 +280,10 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
     const uint32_t orig = d_orig_size[b];
     const unsigned long long coff = d_comp_off[b];
     const uint32_t csize = d_comp_size[b];
-    // Two instantiations of this kernel are launched over the same blocks: the short-code one (MULTI, tables that
-    // yield several symbols per lookup) takes blocks that average < 6.5 bits per symbol, the other one the rest.
     {
-        const bool short_codes = (unsigned long long)csize * 16ull < (unsigned long long)orig * 13ull;
-        if (short_codes != MULTI) return;  // workgroup-uniform; the other launch owns this block
+        const int cls = ((unsigned long long)csize * 16ull >= (unsigned long long)orig * 13ull) ? 4
+                        : ((unsigned long long)orig * 4ull <= (unsigned long long)csize * 9ull) ? 2 : 1;
+        if ((cls & CMASK) == 0) return;  // workgroup-uniform; another launch owns this block
     }
 
     // ---- per-block tables (rebuildCodes: CpuCompressionService.java:582-586 -> CanonicalHuffman.java:99-132) ----
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
             for (int s = 0; s < NS; s++) {
                 ce[s] = oe[s] < cend ? oe[s] : cend;
                 if constexpr (LdsT::PRIV > 0) {
-                    static_assert(LdsT::PRIV <= 64, "a parked run crosses at most one tile pad");
+                    static_assert(LdsT::PRIV <= 112, "a parked run crosses at most two tile pads");
                     // a wholly parked subsequence that lies inside this flush: OR its registers into the tile,
                     // shifted to the byte phase of its first symbol (bytes outside the run are zero)
                     if (park && nsym[s] <= (uint32_t)LdsT::PRIV && oi[s] == os[s] && oi[s] < oe[s] && oe[s] <= cend) {
@@ -761,7 +766,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? DCZ_K4_MINWAVES : 1) void
                             const uint32_t cur = (k < NR) ? R[s][k < NR ? k : 0] : 0u;
                             const uint32_t v = __builtin_amdgcn_perm(cur, prev, sel);
                             prev = cur;
-                            atomicOr(tp + k + ((uint32_t)k >= kc ? 1 : 0), v);  // OR-ing zero is a no-op: no guard
+                            uint32_t pads = ((uint32_t)k >= kc) ? 1u : 0u;
+                            if (k > 16) pads += ((uint32_t)k >= kc + 16u) ? 1u : 0u;
+                            atomicOr(tp + k + pads, v);  // OR-ing zero is a no-op: no guard
                         }
                         oi[s] = oe[s];
                     }
@@ -896,14 +903,21 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     }();
     if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false>), dim3(K), dim3(DCZ_K4_W), 0, s,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4>), dim3(K), dim3(DCZ_K4_W), 0,
+                           s, d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#if DCZ_K4_PRIVM > 0
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2>), dim3(K), dim3(DCZ_K4_W), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp, comp_bytes,
-                           off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-    } else {
-        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false>), dim3(K), dim3(1024), 0, s, d_comp,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 1>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
                            comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
+#else
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 3>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
+                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#endif
+    } else {
+        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4>), dim3(K), dim3(1024), 0, s,
+                           d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 3>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
     }
 }
