@@ -61,6 +61,9 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4_PRIVM
 #define DCZ_K4_PRIVM 96  // parking capacity of the instantiation for medium code lengths (3.6 .. 6.5 bits), 0 = none
 #endif
+#ifndef DCZ_K4S_PRIVM
+#define DCZ_K4S_PRIVM 96
+#endif
 #ifndef DCZ_K4S_PRIV
 #define DCZ_K4S_PRIV 64
 #endif
@@ -917,8 +920,15 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     } else {
         hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4>), dim3(K), dim3(1024), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#if DCZ_K4S_PRIVM > 0
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2>), dim3(K), dim3(1024), 0, s, d_comp,
+                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 1>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
+                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#else
         hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 3>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#endif
     }
 }
 
