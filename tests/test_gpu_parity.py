@@ -463,3 +463,90 @@ def test_periodic_runs_inside_a_block(svc, orc, period_len):
     lens, _ = orc.build_canonical_codes(orc.histogram(data))
     assert_parity(svc, orc, data, data.size)
     assert_parity(svc, orc, data[: (data.size // 5) * 5], data.size // 5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K4 decodes a block by one of three strategies chosen from its average code length (>= 6.5 bits: 48 parked
+# symbols per subsequence; <= 72 expected symbols per subsequence: 96 parked symbols; shorter: multi-symbol
+# tables) and by one of two launch shapes (>= 1024 blocks / fewer).  These streams sit inside and on the edges
+# of every class, include codewords longer than the 11-bit table, and make windows overflow one tile flush.
+def _skewed(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "hi7":        # ~7 bits/symbol + rare symbols (long codes)
+        p = np.r_[np.full(128, 1.0), np.full(128, 2e-4)]
+    elif kind == "hi7_5":    # between 7 and 8 bits: a window's output exceeds one flush of the tile
+        p = np.r_[np.full(180, 1.0), np.full(76, 1e-3)]
+    elif kind == "edge6_5":  # blocks fall on both sides of the 6.5-bit class boundary
+        p = np.r_[np.full(90, 1.0), np.full(166, 3e-4)]
+    elif kind == "mid6":     # 6 bits + rare symbols
+        p = np.r_[np.full(64, 1.0), np.full(192, 5e-5)]
+    elif kind == "mid4":     # geometric, ~4.1 bits
+        p = 0.85 ** np.arange(256)
+    elif kind == "edge3_5":  # geometric, ~3.5 bits: blocks on both sides of the 72-symbols-per-subsequence boundary
+        p = 0.785 ** np.arange(256)
+    else:
+        raise ValueError(kind)
+    p = p / p.sum()
+    return rng.choice(256, size=n, p=p).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind", ["hi7", "hi7_5", "edge6_5", "mid6", "mid4", "edge3_5"])
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
+def test_parity_code_length_classes(svc, orc, kind, shape):
+    if shape == "many_blocks":
+        bb, n = 65536, 1100 * 65536 + 4321   # 1101 blocks: the 256-thread kernels
+    else:
+        bb, n = 262144, 40 * 262144 + 12345  # 41 blocks: the 1024-thread kernels
+    data = _skewed(kind, n, seed=len(kind) * 131 + len(shape))
+    blk = assert_parity(svc, orc, data, bb)
+    sizes = blk.comp_size.cpu().numpy().astype(np.float64)
+    bits = 8.0 * sizes[:-1].mean() / bb
+    lo, hi = {"hi7": (6.9, 7.2), "hi7_5": (7.3, 7.8), "edge6_5": (6.4, 6.6), "mid6": (5.9, 6.2), "mid4": (3.9, 4.4),
+              "edge3_5": (3.4, 3.7)}[kind]
+    assert lo < bits < hi, "generator drifted away from the class it is meant to exercise: %.3f bits/symbol" % bits
+
+
+def test_corrupt_and_foreign_blocks_in_the_many_blocks_regime(pkg, svc, orc):
+    """Per-block status / error position / bytes against the oracle's decoder when some of >= 1024 blocks are damaged.
+    The table is prefix-free but incomplete (Kraft sum < 1), so damaged streams do hit bit patterns without a codeword
+    ('Huffman decode error at position i', TableBasedHuffmanDecoder.java:109-111)."""
+    torch = _torch()
+    rng = np.random.default_rng(17)
+    lens = np.zeros(256, np.int32)
+    syms = rng.choice(256, size=48, replace=False)
+    lens[syms] = rng.integers(6, 14, size=48)
+    codes, _ = orc.canonical_codes(lens)
+    K, nsym = 1040, 6000
+    pays, want = [], []
+    for k in range(K):
+        data = rng.choice(syms, size=nsym).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        pay = pay.copy()
+        if k % 5 == 2:  # flip one bit somewhere
+            i = int(rng.integers(0, pay.size))
+            pay[i] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if k % 11 == 7:  # truncate: the reference reads zeros past the end
+            pay = pay[: pay.size // 2]
+        try:
+            want.append((0, 0, orc.decode_block(pay, lens, nsym)))
+        except orc.DecodeError as e:
+            want.append((pkg.native.DCZ_E_BADSTREAM, e.position, None))
+        pays.append(pay)
+    sizes = np.array([p.size for p in pays], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
+    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
+    stride = (nsym + 15) & ~15
+    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                        torch.full((K,), nsym, dtype=torch.int32, device="cuda"),
+                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
+    torch.cuda.synchronize()
+    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
+    nerr = 0
+    for k, (wst, wpos, wdata) in enumerate(want):
+        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
+        if wst:
+            nerr += 1
+            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
+        else:
+            assert (out[k * stride:k * stride + nsym] == wdata).all(), "block %d decodes differently" % k
+    assert nerr > 20  # the case is only meaningful if damage does produce decode errors
