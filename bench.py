@@ -172,6 +172,16 @@ def main():
             except Exception:
                 traffic = None
         value = world * per_gpu * args.steps / elapsed / 1e9
+        # encode and decode separately (rank 0's own times).  t_dec = the K4 launches of a step,
+        # t_enc = the rest of the step (K1/K2/K3 overlap on two streams, so their kernel times do not add up).
+        step_ms = 1e3 * elapsed / args.steps
+        t_dec = kern["k4_decode"]["ms_total"] / args.steps
+        t_enc = max(step_ms - t_dec, 1e-9)
+        split = {"t_enc_ms": round(t_enc, 4), "t_dec_ms": round(t_dec, 4),
+                 "enc_alg_gbps": round((2 * per_gpu + comp_bytes) / (t_enc * 1e-3) / 1e9, 2),
+                 "dec_alg_gbps": round((per_gpu + comp_bytes) / (t_dec * 1e-3) / 1e9, 2) if t_dec > 0 else None,
+                 "enc_read_gbps": round(2 * per_gpu / (t_enc * 1e-3) / 1e9, 2),
+                 "enc_read_frac_of_peak": round(2 * per_gpu / (t_enc * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         line = {
             "metric": "encode+decode GB/s (input bytes)", "value": round(value, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,6 +200,7 @@ def main():
                                    "achieved": round(world * (3 * per_gpu + 2 * comp_bytes) * args.steps / elapsed / 1e9, 2),
                                    "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                                    "frac": round((3 * per_gpu + 2 * comp_bytes) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS, 4)},
+            "split": split,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in kern.items()},
         }
