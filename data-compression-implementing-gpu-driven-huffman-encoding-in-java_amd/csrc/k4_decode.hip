@@ -100,6 +100,7 @@ struct DecLds {
     // of a subsequence started at its true entry, so phase B ORs them into the (zeroed) tile as whole dwords
     // instead of decoding again.
     static constexpr int PRIV = PV;
+    static constexpr bool ZT = PV > 0 || MULTI;  // the tile is kept zero outside the bytes already written
     static_assert(PRIV % 4 == 0, "whole registers");
     uint32_t cend_vote;
     uint32_t flag[3];
@@ -108,7 +109,7 @@ struct DecLds {
     //   mcount: (symbols << 4) | bits                      -> phase A skips several symbols per lookup
     //   mout:   s0 | s1 << 8 | s2 << 16 | bits << 24 | symbols << 28 (first <= 3 symbols) -> phase B
     uint16_t mcount[MULTI ? (1 << TB) : 1];
-    uint32_t mout[MULTI ? (1 << TB) : 1];
+    uint32_t mout[MULTI ? (1 << TB) : 1];  // symbols > 3: a run of the first canonical symbol (bits = all of them)
     uint16_t exits[NSUB];
     unsigned long long lim[40];  // lim[l] = (first[l] + cnt[l]) << (32 - l): exclusive left-aligned upper bound of length l
     uint32_t first[34];
@@ -352,17 +353,20 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         L.table[idx] = (uint16_t)e;
     }
 
-    if constexpr (LdsT::PRIV > 0) {  // the tile is OR-ed into: start from zero
+    if constexpr (LdsT::ZT) {  // the tile is OR-ed into / runs of zero bytes are skipped: start from zero
         for (int i = tid; i < (int)(sizeof(L.outbuf) / 4); i += W) L.outbuf[i] = 0;
     }
     if constexpr (MULTI) {
         __syncthreads();  // L.table complete
         for (int idx = tid; idx < (1 << TB); idx += W) {
             uint32_t pos = 0, cnt = 0, out = 0, bits3 = 0, cnt3 = 0;
+            bool allz = true;  // every codeword of the window is the first canonical symbol (the shortest code)
+            const uint32_t z = L.symtab[0];
             while (pos < (uint32_t)TB) {
                 const uint32_t e = L.table[((uint32_t)idx << pos) & ((1u << TB) - 1u)];
                 const uint32_t len = e >> 8;
                 if (e == 0 || len > (uint32_t)TB - pos) break;  // escape, or the codeword leaves the window
+                allz = allz && (e & 0xFFu) == z;
                 if (cnt < 3) {
                     out |= (e & 0xFFu) << (8 * cnt);
                     bits3 = pos + len;
@@ -372,9 +376,13 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 cnt++;
             }
             L.mcount[idx] = (uint16_t)(cnt ? ((cnt << 4) | pos) : 0u);
-            L.mout[idx] = cnt3 ? (out | (bits3 << 24) | (cnt3 << 28)) : 0u;
+            // a window that holds more than 3 codewords, all of them the shortest code: one RUN entry (count > 3)
+            if (cnt > 3u && allz) L.mout[idx] = out | (pos << 24) | (cnt << 28);
+            else L.mout[idx] = cnt3 ? (out | (bits3 << 24) | (cnt3 << 28)) : 0u;
         }
     }
+    const uint32_t zsym = L.maxlen ? L.symtab[0] : 0u;           // first canonical symbol and its length: the run
+    const uint32_t zlen = L.maxlen ? L.len8[zsym] : 1u;          // entries of mout
     uint8_t* const oblk = out + (uint64_t)b * out_stride;
     const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
     // virtual byte 0 = 16-byte aligned address at or below the payload start
@@ -798,6 +806,16 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                         }
                     }
                     const uint32_t t = oi[0] + tshift;
+                    if (cnt > 3u) {  // a run of the shortest code: clip it to what this flush still owes
+                        const uint32_t room = ce[0] - oi[0];
+                        if (cnt > room) {
+                            cnt = room;
+                            bits = room * zlen;
+                        }
+                        if (zsym != 0u) {  // block-uniform; a run of 0x00 is already in the zeroed tile
+                            for (uint32_t j = 3; j < cnt; j++) ob[opad(t + j)] = (uint8_t)zsym;
+                        }
+                    }
                     if (a) ob[opad(t)] = (uint8_t)e;
                     if (a && cnt > 1u) ob[opad(t + 1u)] = (uint8_t)(e >> 8);
                     if (a && cnt > 2u) ob[opad(t + 2u)] = (uint8_t)(e >> 16);
@@ -848,13 +866,13 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 } else {
                     for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[opad(i)];
                 }
-                if constexpr (LdsT::PRIV > 0) src[0] = src[1] = src[2] = src[3] = 0;
+                if constexpr (LdsT::ZT) src[0] = src[1] = src[2] = src[3] = 0;
             }
             const uint32_t tail = total - full;  // < 16
             uint8_t tv = 0;
             if ((uint32_t)tid < tail) {
                 tv = ob[opad(full + tid)];
-                if constexpr (LdsT::PRIV > 0) {
+                if constexpr (LdsT::ZT) {
                     if (full > 0u) ob[opad(full + tid)] = 0;
                 }
             }

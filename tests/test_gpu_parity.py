@@ -484,13 +484,20 @@ def _skewed(kind, n, seed):
         p = 0.85 ** np.arange(256)
     elif kind == "edge3_5":  # geometric, ~3.5 bits: blocks on both sides of the 72-symbols-per-subsequence boundary
         p = 0.785 ** np.arange(256)
+    elif kind == "low_nz":   # ~1.2 bits: long runs of a NON-zero dominant byte (run entries of the short-code tables)
+        p = np.full(256, 0.03 / 255)
+        p[0xAA] = 0.97
+    elif kind == "low_2":    # two frequent symbols, ~1.6 bits: short runs, multi-symbol lookups
+        p = np.full(256, 0.04 / 254)
+        p[0x00] = 0.60
+        p[0x20] = 0.36
     else:
         raise ValueError(kind)
     p = p / p.sum()
     return rng.choice(256, size=n, p=p).astype(np.uint8)
 
 
-@pytest.mark.parametrize("kind", ["hi7", "hi7_5", "edge6_5", "mid6", "mid4", "edge3_5"])
+@pytest.mark.parametrize("kind", ["hi7", "hi7_5", "edge6_5", "mid6", "mid4", "edge3_5", "low_nz", "low_2"])
 @pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
 def test_parity_code_length_classes(svc, orc, kind, shape):
     if shape == "many_blocks":
@@ -502,7 +509,7 @@ def test_parity_code_length_classes(svc, orc, kind, shape):
     sizes = blk.comp_size.cpu().numpy().astype(np.float64)
     bits = 8.0 * sizes[:-1].mean() / bb
     lo, hi = {"hi7": (6.9, 7.2), "hi7_5": (7.3, 7.8), "edge6_5": (6.4, 6.6), "mid6": (5.9, 6.2), "mid4": (3.9, 4.4),
-              "edge3_5": (3.4, 3.7)}[kind]
+              "edge3_5": (3.4, 3.7), "low_nz": (1.1, 1.5), "low_2": (1.3, 1.9)}[kind]
     assert lo < bits < hi, "generator drifted away from the class it is meant to exercise: %.3f bits/symbol" % bits
 
 
