@@ -204,6 +204,14 @@ def main():
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in kern.items()},
         }
+        # K5 beside the codec: per-chunk SHA-256 of the resident input, one lane per chunk.
+        # Not part of `value` (8(d) excludes CHECKSUM_* stages).
+        svc.sha256_device(t_in, chunk)
+        ts = time.perf_counter()
+        for _ in range(2):
+            svc.sha256_device(t_in, chunk)
+        line["sha256_per_chunk"] = {"gbps": round(2 * per_gpu / (time.perf_counter() - ts) / 1e9, 2), "chunks": k_local,
+                                    "note": "one lane per chunk; throughput scales with the number of chunks"}
         if world == 1 and args.cpu_sample_mib != 0:
             line["cpu_baseline"] = cpu_baseline(np, args.workload, gen, seed, chunk, args.cpu_sample_mib)
         print(json.dumps(line), flush=True)

@@ -554,6 +554,16 @@ int dcz_ctx_kernel_time(dcz_ctx* c, int kernel, double* total_ms, uint64_t* laun
     return r;
 }
 
+int dcz_sha256_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_bytes, void* d_digests, void* stream) {
+    if (!c || (!d_in && n) || block_bytes == 0 || (!d_digests && n)) return DCZ_E_INVALID;
+    const size_t K = (n + block_bytes - 1) / block_bytes;
+    if (K > 0xFFFFFFFFull) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    launch_sha256(static_cast<const uint8_t*>(d_in), n, block_bytes, (uint32_t)K, static_cast<uint8_t*>(d_digests),
+                  stream ? static_cast<hipStream_t>(stream) : c->stream);
+    return launch_check(c);
+}
+
 int dczu_fill_java_random(dcz_ctx* c, void* d_buf, size_t n, int64_t seed, uint64_t start, void* stream) {
     if (!c || (!d_buf && n) || (start & 3)) return DCZ_E_INVALID;
     DeviceGuard dg(c->device);

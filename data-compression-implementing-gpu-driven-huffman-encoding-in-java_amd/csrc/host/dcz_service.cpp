@@ -143,6 +143,9 @@ void sha_block(uint32_t h[8], const uint8_t* p) {
 }
 }  // namespace
 
+// one lane per chunk on the GPU: below this many chunks in a batch the host loop is faster
+constexpr int64_t kShaGpuMinChunks = 512;
+
 void sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     const size_t full = n / 64;
@@ -283,19 +286,28 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
         host.resize((size_t)bytes);
         if (!fin.read(reinterpret_cast<char*>(host.data()), bytes)) throw IOError("Cannot read " + inputPath);
         metrics_.record("File I/O", now_ns() - t0, bytes);
+        DevBuf din((size_t)bytes), dout((size_t)bytes + 16), dsize((size_t)K * 4), doff((size_t)K * 8), dlen((size_t)K * 256),
+            dstat((size_t)K * 4), dtot(8);
+        hip_check(hipMemcpy(din.p, host.data(), (size_t)bytes, hipMemcpyHostToDevice), "H2D");
         t0 = now_ns();
-        for (int64_t k = 0; k < K; k++) {
-            const int64_t off = k * cb, len = std::min<int64_t>(cb, bytes - off);
-            uint8_t d[32];
-            sha256(host.data() + off, (size_t)len, d);
-            digests.insert(digests.end(), d, d + 32);
+        if (K >= kShaGpuMinChunks) {  // K5: one lane per chunk on the device-resident batch
+            DevBuf ddig((size_t)K * 32);
+            dcz_check(ctx_, dcz_sha256_blocks(ctx_, din.p, (size_t)bytes, (size_t)cb, ddig.p, nullptr), "dcz_sha256_blocks");
+            hip_check(hipDeviceSynchronize(), "sha256");
+            const size_t at = digests.size();
+            digests.resize(at + (size_t)K * 32);
+            hip_check(hipMemcpy(digests.data() + at, ddig.p, (size_t)K * 32, hipMemcpyDeviceToHost), "D2H digests");
+        } else {
+            for (int64_t k = 0; k < K; k++) {
+                const int64_t off = k * cb, len = std::min<int64_t>(cb, bytes - off);
+                uint8_t d[32];
+                sha256(host.data() + off, (size_t)len, d);
+                digests.insert(digests.end(), d, d + 32);
+            }
         }
         metrics_.record("Checksum Computation", now_ns() - t0, bytes);
 
         t0 = now_ns();
-        DevBuf din((size_t)bytes), dout((size_t)bytes + 16), dsize((size_t)K * 4), doff((size_t)K * 8), dlen((size_t)K * 256),
-            dstat((size_t)K * 4), dtot(8);
-        hip_check(hipMemcpy(din.p, host.data(), (size_t)bytes, hipMemcpyHostToDevice), "H2D");
         dcz_check(ctx_, dcz_compress_blocks(ctx_, din.p, (size_t)bytes, (size_t)cb, dout.p, (size_t)bytes + 16,
                                             dsize.as<uint32_t>(), doff.as<uint64_t>(), dlen.as<uint8_t>(),
                                             dstat.as<int32_t>(), dtot.as<uint64_t>(), nullptr),
@@ -429,6 +441,20 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
                 throw IOError("Chunk decompression failed: Huffman decode error at position " + std::to_string(epos[k]));
             if (stat[k] != DCZ_OK) throw IOError(std::string("Chunk decompression failed: ") + dcz_strerror(stat[k]));
         }
+        // K5 when the decoded chunks are contiguous on the device (all but the last fill the stride) and numerous
+        std::vector<uint8_t> gpu_digests;
+        {
+            bool contiguous = (int64_t)K >= kShaGpuMinChunks;
+            for (size_t k = 0; contiguous && k + 1 < K; k++) contiguous = header.chunks[c0 + k].originalSize == (int64_t)stride;
+            if (contiguous && header.chunks[c0 + K - 1].originalSize <= (int64_t)stride) {
+                const size_t n_dec = (K - 1) * stride + (size_t)header.chunks[c0 + K - 1].originalSize;
+                DevBuf ddig(K * 32);
+                dcz_check(ctx_, dcz_sha256_blocks(ctx_, dout.p, n_dec, stride, ddig.p, nullptr), "dcz_sha256_blocks");
+                hip_check(hipDeviceSynchronize(), "sha256");
+                gpu_digests.resize(K * 32);
+                hip_check(hipMemcpy(gpu_digests.data(), ddig.p, K * 32, hipMemcpyDeviceToHost), "D2H digests");
+            }
+        }
         std::vector<uint8_t> out(K * stride);
         hip_check(hipMemcpy(out.data(), dout.p, K * stride, hipMemcpyDeviceToHost), "D2H decoded");
         metrics_.record("Decoding", now_ns() - t0, (long long)(K * stride));
@@ -436,7 +462,8 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
             const ChunkMetadata& c = header.chunks[c0 + k];
             t0 = now_ns();
             uint8_t d[32];
-            sha256(out.data() + k * stride, c.originalSize, d);
+            if (!gpu_digests.empty()) std::memcpy(d, &gpu_digests[k * 32], 32);
+            else sha256(out.data() + k * stride, c.originalSize, d);
             if (std::memcmp(d, c.sha256, 32) != 0) {  // CpuCompressionService.java:536-550
                 std::ostringstream o;
                 o << "Checksum mismatch in chunk " << c.chunkIndex << ":\n  Expected: " << hex(c.sha256, 32)

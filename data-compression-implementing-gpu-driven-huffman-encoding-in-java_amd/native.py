@@ -25,7 +25,7 @@ SYMBOLS = [
     "dcz_device_count", "dcz_ctx_create", "dcz_ctx_destroy", "dcz_strerror", "dcz_last_error", "dcz_ctx_reserve",
     "dcz_histogram", "dcz_build_codes", "dcz_codes_from_lengths", "dcz_encode_block", "dcz_decode_block",
     "dcz_compress_blocks", "dcz_decompress_blocks", "dcz_ctx_set_profiling", "dcz_ctx_reset_profiling",
-    "dcz_ctx_kernel_time", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
+    "dcz_ctx_kernel_time", "dcz_sha256_blocks", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
 ]
 
 _lib = None
@@ -86,6 +86,8 @@ def lib():
     L.dcz_ctx_reset_profiling.restype = i32
     L.dcz_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
     L.dcz_ctx_kernel_time.restype = i32
+    L.dcz_sha256_blocks.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.dcz_sha256_blocks.restype = i32
     L.dczu_fill_java_random.argtypes = [vp, vp, sz, C.c_int64, u64, vp]
     L.dczu_fill_java_random.restype = i32
     L.dczu_fill_text.argtypes = [vp, vp, sz, u64, u64, vp]

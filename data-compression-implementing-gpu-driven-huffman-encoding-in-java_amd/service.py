@@ -175,6 +175,22 @@ class HipCompressionService:
             errpos.data_ptr(), s))
         return t_out, status, errpos
 
+    def sha256_device(self, t, block_bytes, stream=None):
+        """SHA-256 of every block of a device buffer (ChecksumUtil.computeSha256 per chunk) -> uint8 tensor [K, 32]."""
+        torch = self.torch
+        n = int(t.numel())
+        bb = int(block_bytes)
+        K = (n + bb - 1) // bb
+        out = torch.empty((max(K, 1), 32), dtype=torch.uint8, device=t.device)
+        s = stream if stream is not None else torch.cuda.current_stream(t.device).cuda_stream
+        self.ctx.check(nv.lib().dcz_sha256_blocks(self.ctx.handle, t.data_ptr(), n, bb, out.data_ptr(), s))
+        if stream is None:  # the digests are read by the host next: wait for the context's stream
+            torch.cuda.synchronize(t.device)
+        return out[:K]
+
+    # one lane per chunk: below this many chunks in a batch the host's hashlib is faster
+    SHA_GPU_MIN_CHUNKS = 512
+
     # ---- single chunk, host bytes (processChunk / decodeChunkParallel hot stages) ------------
     def encode_chunk(self, data):
         """-> (payload ndarray, code_lengths int32[256])."""
@@ -232,12 +248,16 @@ class HipCompressionService:
                 raw = fin.read((c1 - c0) * cb)
                 m.record("File I/O", time.perf_counter_ns() - t0, len(raw))
                 host = np.frombuffer(raw, dtype=np.uint8)
+                t_in = torch.from_numpy(host.copy()).to(dev)
                 t0 = time.perf_counter_ns()
-                for k in range(c0, c1):
-                    digests.append(hashlib.sha256(raw[(k - c0) * cb:(k - c0 + 1) * cb]).digest())
+                if c1 - c0 >= self.SHA_GPU_MIN_CHUNKS:  # K5 on the device-resident batch
+                    dg = self.sha256_device(t_in, cb).cpu().numpy()
+                    digests.extend(dg[i].tobytes() for i in range(c1 - c0))
+                else:
+                    for k in range(c0, c1):
+                        digests.append(hashlib.sha256(raw[(k - c0) * cb:(k - c0 + 1) * cb]).digest())
                 m.record("Checksum Computation", time.perf_counter_ns() - t0, len(raw))
                 t0 = time.perf_counter_ns()
-                t_in = torch.from_numpy(host.copy()).to(dev)
                 blocks = self.compress_device(t_in, cb)
                 torch.cuda.synchronize(dev)
                 status = blocks.status.cpu().numpy()
@@ -316,12 +336,17 @@ class HipCompressionService:
                 cause = (HuffmanDecodeError(int(errpos[k].item())) if st[k] == nv.DCZ_E_BADSTREAM
                          else nv.DczError(int(st[k])))
                 raise IOError("Chunk decompression failed") from cause  # CpuCompressionService.java:469-471
+            gpu_digests = None
+            if (len(batch) >= self.SHA_GPU_MIN_CHUNKS and all(c.original_size == stride for c in batch[:-1])
+                    and batch[-1].original_size <= stride):  # decoded chunks are contiguous: hash them where they are
+                n_dec = (len(batch) - 1) * stride + batch[-1].original_size
+                gpu_digests = self.sha256_device(t_out[:n_dec], stride).cpu().numpy()
             out = t_out.cpu().numpy()
             m.record("Decoding", time.perf_counter_ns() - t0, int(sum(c.original_size for c in batch)))
             for i, c in enumerate(batch):
                 t0 = time.perf_counter_ns()
                 dec = out[i * stride:i * stride + c.original_size]
-                actual = hashlib.sha256(dec.tobytes()).digest()
+                actual = gpu_digests[i].tobytes() if gpu_digests is not None else hashlib.sha256(dec.tobytes()).digest()
                 if actual != c.sha256:  # CpuCompressionService.java:536-550
                     raise IOError("Checksum mismatch in chunk %d:\n  Expected: %s\n  Actual:   %s\n"
                                   "  Chunk size: %d bytes\n  Compressed size: %d bytes\n  Compressed offset: %d" % (

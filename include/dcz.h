@@ -134,6 +134,14 @@ int dcz_ctx_set_profiling(dcz_ctx* ctx, int on);
 int dcz_ctx_reset_profiling(dcz_ctx* ctx);
 int dcz_ctx_kernel_time(dcz_ctx* ctx, int kernel, double* total_ms, uint64_t* launches);
 
+/* ---- checksums ------------------------------------------------ */
+
+/* SHA-256 of each of the K = ceil(n / block_bytes) blocks of a device-resident buffer, 32 bytes per block into
+ * d_digests (device): ChecksumUtil.computeSha256(byte[],int,int) (util/ChecksumUtil.java:11-27) as called per chunk by
+ * CpuCompressionService.processChunk (service/cpu/CpuCompressionService.java:224-231) and by the decompressor's
+ * verification (:536-550).  One lane per block: worth using when there are >= ~1000 blocks. */
+int dcz_sha256_blocks(dcz_ctx* ctx, const void* d_in, size_t n, size_t block_bytes, void* d_digests, void* stream);
+
 /* ---- reproducible inputs (util/TestDataGenerator.java:26-73) on the device ------------------- */
 
 /* java.util.Random(seed).nextBytes stream, bytes [start, start+n); start must be a multiple of 4. */

@@ -557,3 +557,63 @@ def test_corrupt_and_foreign_blocks_in_the_many_blocks_regime(pkg, svc, orc):
         else:
             assert (out[k * stride:k * stride + nsym] == wdata).all(), "block %d decodes differently" % k
     assert nerr > 20  # the case is only meaningful if damage does produce decode errors
+
+
+# ---------------------------------------------------------------------------------------------------
+# K5: per-chunk SHA-256 (ChecksumUtil.computeSha256, util/ChecksumUtil.java:11-27) against hashlib and the FIPS 180-4
+# example messages.
+def test_sha256_known_answers(svc):
+    torch = _torch()
+    kats = [(b"abc", "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"),
+            (b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq",
+             "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1"),
+            (b"a" * 1000000, "cdc76e5c9914fb9281a1c7e284d73e67f1809a48a497200e046d39ccc7112cd0")]
+    for msg, want in kats:
+        t = torch.from_numpy(np.frombuffer(msg, dtype=np.uint8).copy()).cuda()
+        got = svc.sha256_device(t, len(msg)).cpu().numpy()
+        assert got.shape == (1, 32) and got[0].tobytes().hex() == want
+
+
+@pytest.mark.parametrize("n,bb", [(1, 1), (55, 55), (56, 56), (63, 64), (64, 64), (65, 64), (119, 120), (1000, 7),
+                                  (3 * 4096 + 17, 4096), (2000 * 1024 + 1, 1024), (33 * 100003, 100003)])
+def test_sha256_blocks_match_hashlib(svc, n, bb):
+    torch = _torch()
+    data = np.random.default_rng(n * 31 + bb).integers(0, 256, size=n, dtype=np.uint8)
+    for shift in (0, 3):  # 16-byte aligned and unaligned block starts
+        t = torch.zeros(n + shift, dtype=torch.uint8, device="cuda")
+        t[shift:] = torch.from_numpy(data).cuda()
+        got = svc.sha256_device(t[shift:], bb).cpu().numpy()
+        K = (n + bb - 1) // bb
+        assert got.shape == (K, 32)
+        for k in range(K):
+            assert got[k].tobytes() == hashlib.sha256(data[k * bb:(k + 1) * bb].tobytes()).digest(), (n, bb, shift, k)
+
+
+def test_file_service_uses_device_checksums_for_many_chunks(svc, pkg, orc, tmp_path):
+    """Above SHA_GPU_MIN_CHUNKS chunks per batch the container's per-chunk digests come from K5; the file must still be
+    the oracle's, byte for byte, and must verify."""
+    old_cs, old_min = svc.chunk_size_bytes, svc.SHA_GPU_MIN_CHUNKS
+    try:
+        svc.chunk_size_bytes = 4096
+        svc.SHA_GPU_MIN_CHUNKS = 8
+        data = orc.gen_text(99, 0, 600 * 4096 + 1234)
+        src = tmp_path / "many.bin"
+        src.write_bytes(data.tobytes())
+        out = tmp_path / "many.dcz"
+        svc.compress(str(src), str(out))
+        blob = out.read_bytes()
+        header, start = pkg.container.locate_header(blob)
+        for c in header.chunks:
+            assert c.sha256 == hashlib.sha256(data[c.original_offset:c.original_offset + c.original_size].tobytes()).digest()
+        back = tmp_path / "many.out"
+        svc.decompress(str(out), str(back))
+        assert back.read_bytes() == data.tobytes()
+        assert svc.verify_integrity(str(out))
+        # a damaged payload byte must be caught by the (device) checksum verification
+        bad = bytearray(blob)
+        bad[100] ^= 0x40
+        (tmp_path / "bad.dcz").write_bytes(bytes(bad))
+        with pytest.raises(IOError):
+            svc.decompress(str(tmp_path / "bad.dcz"), str(tmp_path / "bad.out"))
+    finally:
+        svc.chunk_size_bytes, svc.SHA_GPU_MIN_CHUNKS = old_cs, old_min
