@@ -617,3 +617,12 @@ def test_file_service_uses_device_checksums_for_many_chunks(svc, pkg, orc, tmp_p
             svc.decompress(str(tmp_path / "bad.dcz"), str(tmp_path / "bad.out"))
     finally:
         svc.chunk_size_bytes, svc.SHA_GPU_MIN_CHUNKS = old_cs, old_min
+
+
+@pytest.mark.parametrize("kind", ["text", "lowentropy", "random"])
+def test_parity_cli_default_32mib_blocks(svc, orc, kind):
+    """The reference CLI's default chunk size (cli/DataCompCLI.java: 32 MB): two full blocks and a ragged third."""
+    n = 2 * (32 << 20) + 1234567
+    data = {"text": lambda: orc.gen_text(0xD0C2, 0, n), "lowentropy": lambda: orc.gen_lowentropy(0xD0C5, 0, n),
+            "random": lambda: orc.java_random_bytes(42, n)}[kind]()
+    assert_parity(svc, orc, data, 32 << 20)
