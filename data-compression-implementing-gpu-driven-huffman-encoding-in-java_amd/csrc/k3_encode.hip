@@ -39,6 +39,8 @@ constexpr int K3_COPIES = DCZ_K3_COPIES;  // codebook replicas: 32 would be conf
 constexpr int K3_CSHIFT = (K3_COPIES == 32) ? 5 : (K3_COPIES == 16) ? 4 : (K3_COPIES == 8) ? 3 : 2;
 constexpr int RING_WORDS = 1024;     // 4 KiB per wave = 32768 bits
 constexpr uint32_t RING_MASK = RING_WORDS - 1;
+constexpr int RING_STRIDE = RING_WORDS + 4;  // + 2 slack dwords (a string that starts in the last dwords spills into
+                                             // them and is folded back to dwords 0/1 by the next flush) + 2 pad
 
 struct EncState {
     uint32_t* ring;   // per-wave LDS ring (big-endian bit order inside each dword)
@@ -47,21 +49,20 @@ struct EncState {
     uint32_t rflush;  // next byte to store, relative to the origin
 };
 
-// OR the low `l` bits of g (1 <= l <= 64) into the ring at relative bit position p.
+// OR the low `l` bits of g (0 <= l <= 64) into the ring at relative bit position p.  The string is left-aligned in 64
+// bits and spread over three consecutive dwords with funnel shifts; the dwords are OR-ed unconditionally (a zero does
+// nothing), their addresses are the first one plus immediates -- the ring has two slack dwords past its end.
 __device__ __forceinline__ void ring_or(uint32_t* ring, uint32_t p, unsigned long long g, uint32_t l) {
-    if (l == 0) return;
-    const unsigned long long ga = g << (64u - l);
-    const uint32_t sh = p & 31u;
-    const uint32_t w0 = p >> 5;
-    const unsigned long long t = ga >> sh;
-    const uint32_t x0 = (uint32_t)(t >> 32), x1 = (uint32_t)t;
-    __hip_atomic_fetch_or(&ring[w0 & RING_MASK], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (sh + l > 32u)
-        __hip_atomic_fetch_or(&ring[(w0 + 1) & RING_MASK], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (sh + l > 64u) {
-        const uint32_t x2 = (uint32_t)((((unsigned long long)(uint32_t)ga) << 32) >> sh);
-        __hip_atomic_fetch_or(&ring[(w0 + 2) & RING_MASK], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
+    const unsigned long long ga = l ? (g << (64u - l)) : 0ull;
+    const uint32_t hi = (uint32_t)(ga >> 32), lo = (uint32_t)ga;
+    const uint32_t sh = p;  // v_alignbit uses the low 5 bits
+    const uint32_t x0 = hi >> (sh & 31u);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(hi, lo, sh);
+    const uint32_t x2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
+    uint32_t* q = ring + ((p >> 5) & RING_MASK);
+    __hip_atomic_fetch_or(q, x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(q + 1, x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(q + 2, x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 __device__ __forceinline__ uint32_t ring_byte(const uint32_t* ring, uint32_t rb) {
@@ -72,6 +73,14 @@ __device__ __forceinline__ uint32_t ring_byte(const uint32_t* ring, uint32_t rb)
 // Store every relative byte in [st.rflush, upto) and zero the ring chunks that are completely done.
 // `upto` is wave-uniform.  Whole 16-byte chunks go out as one dwordx4 per lane.
 __device__ __forceinline__ void ring_flush(EncState& st, uint32_t upto, int lane) {
+    wave_lds_fence();
+    if (lane < 2) {  // fold the slack dwords (spill of strings that started in the ring's last two dwords) back in
+        const uint32_t v = st.ring[RING_WORDS + lane];
+        if (v) {
+            __hip_atomic_fetch_or(&st.ring[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            st.ring[RING_WORDS + lane] = 0u;
+        }
+    }
     wave_lds_fence();
     while (st.rflush < upto) {
         const uint32_t f = st.rflush;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                                                             const int32_t* __restrict__ d_status,
                                                             uint8_t* __restrict__ out) {
     // one array: [0, 8192) codebook (32 KiB), then 8 rings of 1024 dwords (32 KiB)
-    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * K3_COPIES + K3_WAVES * RING_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * K3_COPIES + K3_WAVES * RING_STRIDE];
     const uint32_t b = blockIdx.x / groups_per_block;
     const uint32_t grp = blockIdx.x % groups_per_block;
     const int tid = (int)threadIdx.x;
@@ -258,11 +267,12 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
             lut64[s] = ((unsigned long long)d_code[(uint64_t)b * 256u + s] << 8) |
                        (unsigned long long)d_len[(uint64_t)b * 256u + s];
     }
-    uint32_t* ring = lds + 256 * K3_COPIES + w * RING_WORDS;
+    uint32_t* ring = lds + 256 * K3_COPIES + w * RING_STRIDE;
     {
         uint4* r4 = reinterpret_cast<uint4*>(ring);
 #pragma unroll
         for (int i = 0; i < RING_WORDS / 4 / 64; i++) r4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) r4[RING_WORDS / 4] = make_uint4(0, 0, 0, 0);  // slack
     }
     __syncthreads();
 
