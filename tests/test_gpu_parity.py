@@ -626,3 +626,101 @@ def test_parity_cli_default_32mib_blocks(svc, orc, kind):
     data = {"text": lambda: orc.gen_text(0xD0C2, 0, n), "lowentropy": lambda: orc.gen_lowentropy(0xD0C5, 0, n),
             "random": lambda: orc.java_random_bytes(42, n)}[kind]()
     assert_parity(svc, orc, data, 32 << 20)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Seeded fuzz: arbitrary sizes, block sizes and byte distributions (sparse alphabets, heavy skew, long codes), every
+# artefact compared with the oracle.  Deterministic (fixed seeds), 300 cases.
+def _fuzz_case(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 70000), rng.integers(70000, 3000000)]))
+    kind = int(rng.integers(0, 6))
+    if kind == 0:    # Dirichlet over a random alphabet size
+        k = int(rng.integers(1, 257))
+        p = np.zeros(256)
+        p[rng.choice(256, size=k, replace=False)] = rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.3, 1.0, 10.0]))))
+    elif kind == 1:  # geometric with random ratio over a random permutation of the bytes
+        p = np.zeros(256)
+        p[rng.permutation(256)] = float(rng.uniform(0.3, 0.99)) ** np.arange(256)
+    elif kind == 2:  # Fibonacci-like weights: very long codes
+        d = int(rng.integers(8, 31))
+        w = np.ones(d)
+        for i in range(2, d):
+            w[i] = w[i - 1] + w[i - 2]
+        p = np.zeros(256)
+        p[rng.choice(256, size=d, replace=False)] = w
+    elif kind == 3:  # runs: piecewise constant data with random run lengths
+        vals = rng.integers(0, 256, size=max(1, n // int(rng.integers(1, 200)) + 1), dtype=np.uint8)
+        data = np.repeat(vals, int(rng.integers(1, 200)))[:n]
+        if data.size < n:
+            data = np.resize(data, n)
+        p = None
+    elif kind == 4:  # two-level mix: mostly one byte, the rest uniform
+        p = np.full(256, (1 - float(rng.uniform(0.5, 0.999))) / 255)
+        p[int(rng.integers(0, 256))] = 0
+        p[int(rng.integers(0, 256))] += 1 - p.sum()
+    else:            # uniform over all bytes
+        p = np.ones(256)
+    if p is not None:
+        p = np.maximum(p, 0)
+        data = rng.choice(256, size=n, p=p / p.sum()).astype(np.uint8)
+    bb_kind = int(rng.integers(0, 4))
+    if bb_kind == 0:
+        bb = n
+    elif bb_kind == 1:
+        bb = int(rng.integers(1, n + 1))
+    elif bb_kind == 2:
+        bb = 1 << int(rng.integers(6, 21))
+    else:
+        bb = max(1, n // int(rng.integers(1, 40)))
+    if (n + bb - 1) // bb > 5000:  # keep the number of blocks (oracle time) bounded
+        bb = (n + 4999) // 5000
+    return np.ascontiguousarray(data, dtype=np.uint8), int(bb)
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_fuzz_parity(svc, orc, seed):
+    data, bb = _fuzz_case(1000 + seed)
+    assert_parity(svc, orc, data, bb)
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_fuzz_decode_foreign_and_damaged(pkg, svc, orc, seed):
+    """Single-block decoder (dcz_decode_block) on streams of arbitrary prefix-free tables (complete or not), intact,
+    bit-flipped or truncated: bytes, or the reference's error position, must equal the oracle decoder's."""
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.integers(1, 60))
+    lens = np.zeros(256, np.int32)
+    syms = rng.choice(256, size=k, replace=False)
+    budget = 1.0  # Kraft budget: assign random lengths while the sum of 2^-len stays <= 1
+    for s_ in syms:
+        lo = 1
+        while 2.0 ** -lo > budget and lo < 24:
+            lo += 1
+        if 2.0 ** -lo > budget:
+            break
+        ln = int(rng.integers(lo, min(24, lo + 12) + 1))
+        lens[s_] = ln
+        budget -= 2.0 ** -ln
+    used = np.nonzero(lens)[0]
+    codes, _ = orc.canonical_codes(lens)
+    n = int(rng.integers(1, 60000))
+    data = rng.choice(used, size=n).astype(np.uint8)
+    pay, _ = orc.encode_block(data, lens, codes)
+    pay = pay.copy()
+    mode = int(rng.integers(0, 3))
+    if mode == 1 and pay.size:
+        for _ in range(int(rng.integers(1, 4))):
+            pay[int(rng.integers(0, pay.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    elif mode == 2:
+        pay = pay[: int(rng.integers(0, pay.size + 1))]
+        if pay.size == 0:
+            pay = np.zeros(1, np.uint8)
+    try:
+        want = orc.decode_block(pay, lens, n)
+    except orc.DecodeError as e:
+        with pytest.raises(pkg.HuffmanDecodeError) as he:
+            svc.decode_chunk(pay, lens, n)
+        assert he.value.position == e.position
+        return
+    assert (svc.decode_chunk(pay, lens, n) == want).all()
