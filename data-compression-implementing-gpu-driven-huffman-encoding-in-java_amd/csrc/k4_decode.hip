@@ -70,6 +70,12 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4M_OC
 #define DCZ_K4M_OC 8192  // short-code instantiation, many-blocks kernel
 #endif
+#ifndef DCZ_K4_SPARSE
+#define DCZ_K4_SPARSE 1  // short-code class: fill + single-byte stores for blocks dominated by a 1-bit symbol
+#endif
+#ifndef DCZ_K4L_OC
+#define DCZ_K4L_OC 8192  // short-code instantiation (multi-symbol tables), many-blocks kernel
+#endif
 #ifndef DCZ_K4S_OC
 #define DCZ_K4S_OC 32768 // few-blocks kernel (one 1024-thread workgroup per block owns the CU: use its LDS)
 #endif
@@ -383,6 +389,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     }
     const uint32_t zsym = L.maxlen ? L.symtab[0] : 0u;           // first canonical symbol and its length: the run
     const uint32_t zlen = L.maxlen ? L.len8[zsym] : 1u;          // entries of mout
+    // block-uniform: a 1-bit symbol and < 1.3 bits per symbol on average (from the block's own sizes)
+    const bool sparse = MULTI && DCZ_K4_SPARSE && zlen == 1u && L.maxlen > 1u &&
+                        (unsigned long long)csize * 80ull < (unsigned long long)orig * 13ull;
     uint8_t* const oblk = out + (uint64_t)b * out_stride;
     const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
     // virtual byte 0 = 16-byte aligned address at or below the payload start
@@ -734,7 +743,66 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 oo = end;
             }
         }
-        for (uint32_t cbase = 0; cbase < lim;) {
+        bool direct = false;
+        if constexpr (MULTI) {
+            // Blocks that are almost entirely the 1-bit symbol (< 1.3 bits per symbol on average): the window's output
+            // range is filled with that symbol by wide stores, then every thread walks its subsequence and stores only
+            // the OTHER symbols, one byte each, straight to global memory.  No staging tile, so all subsequences of the
+            // window are expanded at once (through the tile only ~OC/237 threads would work at a time).
+            direct = sparse;
+            if (sparse) {
+                uint8_t* const dst = oblk + produced;  // lim bytes
+                {
+                    uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+                    if (head > lim) head = lim;
+                    if ((uint32_t)tid < head) dst[tid] = (uint8_t)zsym;
+                    const uint32_t body = (lim - head) >> 4;
+                    const uint32_t z4 = zsym * 0x01010101u;
+                    uint4* const d4 = reinterpret_cast<uint4*>(dst + head);
+                    for (uint32_t u = (uint32_t)tid; u < body; u += W) d4[u] = make_uint4(z4, z4, z4, z4);
+                    const uint32_t t0 = head + (body << 4);
+                    if ((uint32_t)tid < lim - t0) dst[t0 + tid] = (uint8_t)zsym;
+                }
+                __threadfence_block();  // the fill is in memory before any thread's single-byte stores
+                __syncthreads();
+                bool any = oi[0] < oe[0];
+                while (any) {
+                    const unsigned long long two = fetch64(np[0]);
+                    const uint32_t off = table_off(two, np[0]);
+                    const bool a = oi[0] < oe[0];
+                    const bool big = a && (oe[0] - oi[0] >= 3u);
+                    uint32_t e;
+                    if (big) e = *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(mout_addr + 2u * off);
+                    else e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + off);
+                    uint32_t bits = big ? ((e >> 24) & 15u) : (e >> 8);
+                    uint32_t cnt = big ? (e >> 28) : 1u;
+                    if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
+                        if (a && e == 0) {
+                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            bits = e >> 8;
+                            cnt = 1;
+                        }
+                    }
+                    if (cnt > 3u) {  // a run of the fill symbol: nothing to store
+                        const uint32_t room = oe[0] - oi[0];
+                        if (cnt > room) {
+                            cnt = room;
+                            bits = room * zlen;
+                        }
+                    } else if (a) {
+                        const uint32_t s0 = e & 0xFFu, s1 = (e >> 8) & 0xFFu, s2 = (e >> 16) & 0xFFu;
+                        if (s0 != zsym) dst[oi[0]] = (uint8_t)s0;
+                        if (cnt > 1u && s1 != zsym) dst[oi[0] + 1u] = (uint8_t)s1;
+                        if (cnt > 2u && s2 != zsym) dst[oi[0] + 2u] = (uint8_t)s2;
+                    }
+                    np[0] -= a ? bits : 0u;
+                    oi[0] += a ? cnt : 0u;
+                    any = oi[0] < oe[0];
+                }
+                gpos += lim;  // nothing is carried: gpos + ocarry == produced stays true (ocarry is 0 in this mode)
+            }
+        }
+        for (uint32_t cbase = 0; !direct && cbase < lim;) {
             uint32_t cc = lim - cbase;
             const uint32_t room = (uint32_t)LdsT::CAP - ocarry;
             if (cc > room) {  // workgroup-uniform: the rest of the window does not fit one flush
@@ -929,7 +997,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 #if DCZ_K4_PRIVM > 0
         hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2>), dim3(K), dim3(DCZ_K4_W), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 1>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
                            comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #else
         hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 3>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,

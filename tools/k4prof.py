@@ -9,7 +9,8 @@ prof = lib.dcz_debug_k4_prof
 prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ["A decode", "staging+sync", "A barrier/check", "scan+err", "prefetch", "B write", "flush", "tail/end"]
 for name, fill, seed, n, bb in [("rand2g", lib.dczu_fill_java_random, 42, 2 << 30, 1 << 20),
-                                ("text2g", lib.dczu_fill_text, 0xD0C2, 2 << 30, 1 << 20)]:
+                                ("text2g", lib.dczu_fill_text, 0xD0C2, 2 << 30, 1 << 20),
+                                ("low2g", lib.dczu_fill_lowentropy, 0xD0C5, 2 << 30, 1 << 20)]:
     t = torch.empty(n, dtype=torch.uint8, device="cuda")
     fill(h, t.data_ptr(), n, seed, 0, None)
     blk = svc.compress_device(t, bb)
