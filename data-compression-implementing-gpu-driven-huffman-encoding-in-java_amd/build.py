@@ -33,7 +33,7 @@ def build_host(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-o", CLI] + srcs + ["-L" + HERE, "-ldczhip", "-Wl,-rpath,$ORIGIN"]
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI] + srcs + ["-L" + HERE, "-ldczhip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <sstream>
+#include <thread>
 
 #include "../../../include/dcz.h"
 
@@ -143,8 +145,9 @@ void sha_block(uint32_t h[8], const uint8_t* p) {
 }
 }  // namespace
 
-// one lane per chunk on the GPU: below this many chunks in a batch the host loop is faster
-constexpr int64_t kShaGpuMinChunks = 512;
+// one lane per chunk on the GPU (~17 MB/s per lane, asynchronous beside the file I/O): below this many chunks in a batch the
+// single-threaded host loop (~0.4 GB/s) is faster
+constexpr int64_t kShaGpuMinChunks = 64;
 
 void sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
@@ -235,6 +238,23 @@ std::vector<int64_t> HipFrequencyService::computeHistogram(const uint8_t* data, 
     return h;
 }
 
+// Chunk-parallel host work with the reference's worker count max(2, min(nproc, 8)) (CpuCompressionService.java:42-44).
+static void parallel_chunks(int64_t n, const std::function<void(int64_t)>& fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t workers = std::min<int64_t>(n, std::max(2u, std::min(hw ? hw : 2u, 8u)));
+    if (workers <= 1) {
+        for (int64_t k = 0; k < n; k++) fn(k);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+    for (int64_t w = 0; w < workers; w++)
+        pool.emplace_back([&]() {
+            for (int64_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) fn(k);
+        });
+    for (auto& t : pool) t.join();
+}
+
 // ---- HipCompressionService ----------------------------------------------------------------------------------------
 HipCompressionService::HipCompressionService(int chunkSizeMB, int device) : device_(device) {
     if (chunkSizeMB <= 0 || chunkSizeMB > 2047) throw std::invalid_argument("chunk size must be 1..2047 MB");
@@ -275,77 +295,146 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
     header.chunkSizeBytes = (int32_t)cb;
     std::vector<uint8_t> digests;  // 32 bytes per chunk, in index order (CpuCompressionService.java:106-109)
 
+    // Streaming pipeline (the reference's GPU service keeps <= 2 chunks in flight,
+    // GpuCompressionService.java:232-320): two slots, each with its own context + stream, pinned host buffers and
+    // device buffers.  While the GPU works on batch i (H2D, K5, K1-K3, D2H of the small arrays -- all asynchronous on
+    // the slot's stream), the host finishes batch i-1 (payload D2H, ordered write) and reads batch i+1.
     const int64_t perBatch = std::max<int64_t>(1, (int64_t)batchBytes_ / cb);
+    const size_t slotBytes = (size_t)std::min<int64_t>(size, perBatch * cb);
+    const size_t slotChunks = (size_t)std::min<int64_t>(numChunks, perBatch);
+    struct Slot {
+        dcz_ctx* ctx = nullptr;
+        bool own_ctx = false;
+        hipStream_t stream = nullptr;
+        uint8_t *hin = nullptr, *hout = nullptr, *hsmall = nullptr;  // pinned
+        void *din = nullptr, *dout = nullptr, *dsize = nullptr, *doff = nullptr, *dlen = nullptr, *dstat = nullptr,
+             *dtot = nullptr, *ddig = nullptr;
+        int64_t c0 = 0, K = 0, bytes = 0;
+        bool busy = false, gpu_sha = false;
+    } slots[2];
+    // layout of the pinned "small" buffer of a slot: sizes u32[K] | status i32[K] | lens u8[K*256] | digests u8[K*32] | total u64
+    const size_t smallBytes = slotChunks * (4 + 4 + 256 + 32) + 8;
+    auto release = [&]() {
+        for (Slot& sl : slots) {
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+            if (sl.hin) (void)hipHostFree(sl.hin);
+            if (sl.hout) (void)hipHostFree(sl.hout);
+            if (sl.hsmall) (void)hipHostFree(sl.hsmall);
+            for (void* p : {sl.din, sl.dout, sl.dsize, sl.doff, sl.dlen, sl.dstat, sl.dtot, sl.ddig})
+                if (p) (void)hipFree(p);
+            if (sl.own_ctx) dcz_ctx_destroy(sl.ctx);
+            sl = Slot();
+        }
+    };
     int64_t compOffset = 0, done = 0;
-    std::vector<uint8_t> host;
-    for (int64_t c0 = 0; c0 < numChunks; c0 += perBatch) {
-        const int64_t c1 = std::min(numChunks, c0 + perBatch);
-        const int64_t bytes = std::min<int64_t>(size - c0 * cb, (c1 - c0) * cb);
-        const int64_t K = c1 - c0;
-        long long t0 = now_ns();
-        host.resize((size_t)bytes);
-        if (!fin.read(reinterpret_cast<char*>(host.data()), bytes)) throw IOError("Cannot read " + inputPath);
-        metrics_.record("File I/O", now_ns() - t0, bytes);
-        DevBuf din((size_t)bytes), dout((size_t)bytes + 16), dsize((size_t)K * 4), doff((size_t)K * 8), dlen((size_t)K * 256),
-            dstat((size_t)K * 4), dtot(8);
-        hip_check(hipMemcpy(din.p, host.data(), (size_t)bytes, hipMemcpyHostToDevice), "H2D");
-        t0 = now_ns();
-        if (K >= kShaGpuMinChunks) {  // K5: one lane per chunk on the device-resident batch
-            DevBuf ddig((size_t)K * 32);
-            dcz_check(ctx_, dcz_sha256_blocks(ctx_, din.p, (size_t)bytes, (size_t)cb, ddig.p, nullptr), "dcz_sha256_blocks");
-            hip_check(hipDeviceSynchronize(), "sha256");
-            const size_t at = digests.size();
-            digests.resize(at + (size_t)K * 32);
-            hip_check(hipMemcpy(digests.data() + at, ddig.p, (size_t)K * 32, hipMemcpyDeviceToHost), "D2H digests");
-        } else {
-            for (int64_t k = 0; k < K; k++) {
-                const int64_t off = k * cb, len = std::min<int64_t>(cb, bytes - off);
-                uint8_t d[32];
-                sha256(host.data() + off, (size_t)len, d);
-                digests.insert(digests.end(), d, d + 32);
+    const int nslots = (numChunks > perBatch) ? 2 : 1;
+    try {
+        for (int i = 0; i < nslots; i++) {
+            Slot& sl = slots[i];
+            if (i == 0) sl.ctx = ctx_;
+            else {
+                if (dcz_ctx_create(device_, &sl.ctx) != DCZ_OK) throw IOError("GPU compression failed: cannot create a second context");
+                sl.own_ctx = true;
             }
+            hip_check(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hin), slotBytes ? slotBytes : 16, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hout), slotBytes + 16, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hsmall), smallBytes, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipMalloc(&sl.din, slotBytes ? slotBytes : 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dout, slotBytes + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dsize, slotChunks * 4 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.doff, slotChunks * 8 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dlen, slotChunks * 256 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dstat, slotChunks * 4 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dtot, 8), "hipMalloc");
+            hip_check(hipMalloc(&sl.ddig, slotChunks * 32 + 16), "hipMalloc");
         }
-        metrics_.record("Checksum Computation", now_ns() - t0, bytes);
-
-        t0 = now_ns();
-        dcz_check(ctx_, dcz_compress_blocks(ctx_, din.p, (size_t)bytes, (size_t)cb, dout.p, (size_t)bytes + 16,
-                                            dsize.as<uint32_t>(), doff.as<uint64_t>(), dlen.as<uint8_t>(),
-                                            dstat.as<int32_t>(), dtot.as<uint64_t>(), nullptr),
-                  "dcz_compress_blocks");
-        hip_check(hipDeviceSynchronize(), "sync");
-        std::vector<uint32_t> sizes((size_t)K);
-        std::vector<int32_t> stat((size_t)K);
-        std::vector<uint8_t> lens((size_t)K * 256);
-        uint64_t total = 0;
-        hip_check(hipMemcpy(sizes.data(), dsize.p, (size_t)K * 4, hipMemcpyDeviceToHost), "D2H sizes");
-        hip_check(hipMemcpy(stat.data(), dstat.p, (size_t)K * 4, hipMemcpyDeviceToHost), "D2H status");
-        hip_check(hipMemcpy(lens.data(), dlen.p, (size_t)K * 256, hipMemcpyDeviceToHost), "D2H lens");
-        hip_check(hipMemcpy(&total, dtot.p, 8, hipMemcpyDeviceToHost), "D2H total");
-        for (int64_t k = 0; k < K; k++)
-            if (stat[(size_t)k] != DCZ_OK)
-                throw IOError("GPU compression failed: chunk " + std::to_string(c0 + k) + ": " + dcz_strerror(stat[(size_t)k]));
-        std::vector<uint8_t> payload((size_t)total);
-        if (total) hip_check(hipMemcpy(payload.data(), dout.p, (size_t)total, hipMemcpyDeviceToHost), "D2H payload");
-        metrics_.record("Encoding", now_ns() - t0, bytes);
-
-        t0 = now_ns();
-        fout.write(reinterpret_cast<const char*>(payload.data()), (std::streamsize)payload.size());
-        metrics_.record("File I/O", now_ns() - t0, (long long)total);
-        for (int64_t k = 0; k < K; k++) {
-            ChunkMetadata m;
-            m.chunkIndex = (int32_t)(c0 + k);
-            m.originalOffset = (c0 + k) * cb;
-            m.originalSize = (uint32_t)std::min<int64_t>(cb, size - (c0 + k) * cb);
-            m.compressedOffset = compOffset;
-            m.compressedSize = sizes[(size_t)k];
-            std::memcpy(m.sha256, &digests[(size_t)(c0 + k) * 32], 32);
-            for (int i = 0; i < 256; i++) m.codeLengths[i] = (int16_t)lens[(size_t)k * 256 + i];
-            header.chunks.push_back(m);
-            compOffset += sizes[(size_t)k];
-            done++;
-            if (progress) progress((double)done / (double)numChunks);  // CpuCompressionService.java:111-114
+        // completes a slot's batch in file order: wait, fetch the payload, write it, record the metadata
+        auto finish = [&](Slot& sl) {
+            if (!sl.busy) return;
+            long long t0 = now_ns();
+            hip_check(hipStreamSynchronize(sl.stream), "sync");
+            const size_t K = (size_t)sl.K;
+            const uint32_t* sizes = reinterpret_cast<const uint32_t*>(sl.hsmall);
+            const int32_t* stat = reinterpret_cast<const int32_t*>(sl.hsmall + K * 4);
+            const uint8_t* lens = sl.hsmall + K * 8;
+            const uint8_t* dig = sl.hsmall + K * 8 + K * 256;
+            uint64_t total = 0;
+            std::memcpy(&total, sl.hsmall + K * (8 + 256 + 32), 8);
+            for (size_t k = 0; k < K; k++)
+                if (stat[k] != DCZ_OK)
+                    throw IOError("GPU compression failed: chunk " + std::to_string(sl.c0 + (int64_t)k) + ": " + dcz_strerror(stat[k]));
+            if (total) {
+                hip_check(hipMemcpyAsync(sl.hout, sl.dout, (size_t)total, hipMemcpyDeviceToHost, sl.stream), "D2H payload");
+                hip_check(hipStreamSynchronize(sl.stream), "sync");
+            }
+            metrics_.record("Encoding", now_ns() - t0, sl.bytes);
+            t0 = now_ns();
+            fout.write(reinterpret_cast<const char*>(sl.hout), (std::streamsize)total);
+            metrics_.record("File I/O", now_ns() - t0, (long long)total);
+            digests.insert(digests.end(), dig, dig + K * 32);  // from K5 or from the host loop below, in file order
+            for (size_t k = 0; k < K; k++) {
+                const int64_t ci = sl.c0 + (int64_t)k;
+                ChunkMetadata m;
+                m.chunkIndex = (int32_t)ci;
+                m.originalOffset = ci * cb;
+                m.originalSize = (uint32_t)std::min<int64_t>(cb, size - ci * cb);
+                m.compressedOffset = compOffset;
+                m.compressedSize = sizes[k];
+                std::memcpy(m.sha256, &digests[(size_t)ci * 32], 32);
+                for (int i = 0; i < 256; i++) m.codeLengths[i] = (int16_t)lens[k * 256 + (size_t)i];
+                header.chunks.push_back(m);
+                compOffset += sizes[k];
+                done++;
+                if (progress) progress((double)done / (double)numChunks);  // CpuCompressionService.java:111-114
+            }
+            sl.busy = false;
+        };
+        int which = 0;
+        for (int64_t c0 = 0; c0 < numChunks; c0 += perBatch, which ^= (nslots - 1)) {
+            Slot& sl = slots[which];
+            finish(sl);  // batch i-2 (same slot) must be out before its buffers are reused; keeps the file order
+            const int64_t c1 = std::min(numChunks, c0 + perBatch);
+            sl.c0 = c0;
+            sl.K = c1 - c0;
+            sl.bytes = std::min<int64_t>(size - c0 * cb, (c1 - c0) * cb);
+            long long t0 = now_ns();
+            if (!fin.read(reinterpret_cast<char*>(sl.hin), sl.bytes)) throw IOError("Cannot read " + inputPath);
+            metrics_.record("File I/O", now_ns() - t0, sl.bytes);
+            const size_t K = (size_t)sl.K;
+            hip_check(hipMemcpyAsync(sl.din, sl.hin, (size_t)sl.bytes, hipMemcpyHostToDevice, sl.stream), "H2D");
+            t0 = now_ns();
+            sl.gpu_sha = sl.K >= kShaGpuMinChunks;
+            if (sl.gpu_sha) {  // K5: one lane per chunk on the device-resident batch
+                dcz_check(sl.ctx, dcz_sha256_blocks(sl.ctx, sl.din, (size_t)sl.bytes, (size_t)cb, sl.ddig, sl.stream), "dcz_sha256_blocks");
+                hip_check(hipMemcpyAsync(sl.hsmall + K * 8 + K * 256, sl.ddig, K * 32, hipMemcpyDeviceToHost, sl.stream), "D2H digests");
+            }
+            dcz_check(sl.ctx, dcz_compress_blocks(sl.ctx, sl.din, (size_t)sl.bytes, (size_t)cb, sl.dout, (size_t)sl.bytes + 16,
+                                                  static_cast<uint32_t*>(sl.dsize), static_cast<uint64_t*>(sl.doff),
+                                                  static_cast<uint8_t*>(sl.dlen), static_cast<int32_t*>(sl.dstat),
+                                                  static_cast<uint64_t*>(sl.dtot), sl.stream),
+                      "dcz_compress_blocks");
+            hip_check(hipMemcpyAsync(sl.hsmall, sl.dsize, K * 4, hipMemcpyDeviceToHost, sl.stream), "D2H sizes");
+            hip_check(hipMemcpyAsync(sl.hsmall + K * 4, sl.dstat, K * 4, hipMemcpyDeviceToHost, sl.stream), "D2H status");
+            hip_check(hipMemcpyAsync(sl.hsmall + K * 8, sl.dlen, K * 256, hipMemcpyDeviceToHost, sl.stream), "D2H lens");
+            hip_check(hipMemcpyAsync(sl.hsmall + K * (8 + 256 + 32), sl.dtot, 8, hipMemcpyDeviceToHost, sl.stream), "D2H total");
+            sl.busy = true;
+            if (!sl.gpu_sha) {  // few chunks: host threads hash them while the GPU encodes (the pinned input stays valid)
+                parallel_chunks(sl.K, [&](int64_t k) {
+                    const int64_t off = k * cb, len = std::min<int64_t>(cb, sl.bytes - off);
+                    sha256(sl.hin + off, (size_t)len, sl.hsmall + K * 8 + K * 256 + (size_t)k * 32);
+                });
+            }
+            metrics_.record("Checksum Computation", now_ns() - t0, sl.bytes);
         }
+        finish(slots[which]);                  // the older of the two outstanding batches first
+        finish(slots[which ^ (nslots - 1)]);
+    } catch (...) {
+        (void)hipDeviceSynchronize();
+        release();
+        throw;
     }
+    release();
     const long long t0 = now_ns();
     sha256(digests.data(), digests.size(), header.globalChecksum);  // digest of digests (:106-109, :126)
     const int64_t footerStart = compOffset;
@@ -458,12 +547,17 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
         std::vector<uint8_t> out(K * stride);
         hip_check(hipMemcpy(out.data(), dout.p, K * stride, hipMemcpyDeviceToHost), "D2H decoded");
         metrics_.record("Decoding", now_ns() - t0, (long long)(K * stride));
+        if (gpu_digests.empty()) {  // host threads, one chunk each
+            gpu_digests.resize(K * 32);
+            parallel_chunks((int64_t)K, [&](int64_t k) {
+                sha256(out.data() + (size_t)k * stride, (size_t)header.chunks[c0 + (size_t)k].originalSize, &gpu_digests[(size_t)k * 32]);
+            });
+        }
         for (size_t k = 0; k < K; k++) {
             const ChunkMetadata& c = header.chunks[c0 + k];
             t0 = now_ns();
             uint8_t d[32];
-            if (!gpu_digests.empty()) std::memcpy(d, &gpu_digests[k * 32], 32);
-            else sha256(out.data() + k * stride, c.originalSize, d);
+            std::memcpy(d, &gpu_digests[k * 32], 32);
             if (std::memcmp(d, c.sha256, 32) != 0) {  // CpuCompressionService.java:536-550
                 std::ostringstream o;
                 o << "Checksum mismatch in chunk " << c.chunkIndex << ":\n  Expected: " << hex(c.sha256, 32)

@@ -100,7 +100,7 @@ class HipCompressionService {
     dcz_ctx* ctx_ = nullptr;
     int device_ = 0;
     int64_t chunkBytes_ = 0;
-    size_t batchBytes_ = (size_t)1 << 30;
+    size_t batchBytes_ = (size_t)256 << 20;  // per pipeline slot (two slots: pinned + device buffers of this size)
     StageMetrics metrics_;
 };
 

@@ -5,11 +5,11 @@ cd $GRAFT_REPO_ROOT
 P=data-compression-implementing-gpu-driven-huffman-encoding-in-java_amd
 python - <<'PY'
 import numpy as np
-np.random.default_rng(5).integers(0, 200, size=600 * (1 << 20) + 12345, dtype=np.uint8).tofile("/tmp/many.bin")
+np.random.default_rng(5).integers(0, 200, size=1500 * (1 << 20) + 12345, dtype=np.uint8).tofile("/tmp/many.bin")
 PY
-$P/dczcli compress /tmp/many.bin /tmp/many.dcz 1
+$P/dczcli compress /tmp/many.bin /tmp/many.dcz 1 | tr "\r" "\n" | grep -v Progress
 $P/dczcli verify /tmp/many.dcz
-$P/dczcli decompress /tmp/many.dcz /tmp/many.out
+$P/dczcli decompress /tmp/many.dcz /tmp/many.out | tr "\r" "\n" | grep -v Progress
 cmp /tmp/many.bin /tmp/many.out && echo "CLI round trip OK"
 python - <<'PY'
 import sys, hashlib
