@@ -724,3 +724,37 @@ def test_fuzz_decode_foreign_and_damaged(pkg, svc, orc, seed):
         assert he.value.position == e.position
         return
     assert (svc.decode_chunk(pay, lens, n) == want).all()
+
+
+def test_contexts_are_independent_across_threads(pkg, orc):
+    """The reference calls the seam from up to 8 pool threads (CpuCompressionService.java:42-44, :94-96): one context per
+    thread must work concurrently on one device (ctypes releases the GIL inside the C ABI)."""
+    import threading
+    results, errors = {}, []
+
+    def work(i):
+        try:
+            svc = pkg.HipCompressionService(1, 0)
+            try:
+                for rep in range(3):
+                    data = orc.gen_text(100 + i, rep * 1000, 300000 + 7919 * i + rep)
+                    pay, lens = svc.encode_chunk(data)
+                    opay, olens = orc.encode_block(data)
+                    assert (lens == olens).all() and pay.size == opay.size and (pay == opay).all()
+                    assert (svc.decode_chunk(pay, lens, data.size) == data).all()
+                    h = svc.frequency_service().compute_histogram(data, 0, data.size) if hasattr(svc, "frequency_service") else None
+                    if h is not None:
+                        assert (np.asarray(h) == np.bincount(data, minlength=256)).all()
+                results[i] = True
+            finally:
+                svc.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 6
