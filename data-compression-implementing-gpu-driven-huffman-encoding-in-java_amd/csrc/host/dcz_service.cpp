@@ -77,15 +77,6 @@ struct BeReader {
     void raw(uint8_t* out, size_t k) { need(k); std::memcpy(out, p + pos, k); pos += k; }
 };
 
-std::vector<uint8_t> read_file(const std::string& path) {
-    std::ifstream f(path, std::ios::binary | std::ios::ate);
-    if (!f) throw IOError("Cannot open " + path);
-    const std::streamsize n = f.tellg();
-    std::vector<uint8_t> v((size_t)n);
-    f.seekg(0);
-    if (n > 0 && !f.read(reinterpret_cast<char*>(v.data()), n)) throw IOError("Cannot read " + path);
-    return v;
-}
 
 }  // namespace
 
@@ -453,17 +444,24 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
     metrics_ = StageMetrics();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     long long t0 = now_ns();
-    const std::vector<uint8_t> file = read_file(path);
-    metrics_.record("File I/O", now_ns() - t0, (long long)file.size());
-    const size_t total = file.size();
+    std::ifstream fin(path, std::ios::binary);
+    if (!fin) throw IOError("Cannot open " + path);
+    fin.seekg(0, std::ios::end);
+    const size_t total = (size_t)fin.tellg();
+    auto read_at = [&](size_t off, uint8_t* dst, size_t n) {
+        fin.clear();
+        fin.seekg((std::streamoff)off);
+        if (n && !fin.read(reinterpret_cast<char*>(dst), (std::streamsize)n)) throw IOError("Cannot read " + path);
+    };
     // probe order of CpuCompressionService.decompress: header-first from the first <= 4096 bytes (:338-358), else the
-    // footer through the trailing pointer with the 0 <= ptr < size-8 check (:366-388)
+    // footer through the trailing pointer with the 0 <= ptr < size-8 check (:366-388).  Only the metadata is read here;
+    // the payload is streamed batch by batch below.
     CompressionHeader header;
     size_t dataStart = 0;
     bool parsed = false;
     {
         std::vector<uint8_t> probe(std::min<size_t>(64 * 1024, total), 0);
-        std::memcpy(probe.data(), file.data(), std::min<size_t>(4096, probe.size()));
+        read_at(0, probe.data(), std::min<size_t>(4096, probe.size()));
         try {
             header = CompressionHeader::read(probe.data(), probe.size());
             size_t sum = 0;
@@ -475,103 +473,198 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
     }
     if (!parsed) {
         if (total < 8) throw IOError("Invalid file format: file too small");
-        BeReader r{file.data() + total - 8, 8};
+        uint8_t p8[8];
+        read_at(total - 8, p8, 8);
+        BeReader r{p8, 8};
         const int64_t ptr = r.i64();
         if (ptr < 0 || (uint64_t)ptr >= total - 8) throw IOError("Invalid footer position: " + std::to_string(ptr));
-        header = CompressionHeader::read(file.data() + ptr, total - 8 - (size_t)ptr);
+        std::vector<uint8_t> footer(total - 8 - (size_t)ptr);
+        read_at((size_t)ptr, footer.data(), footer.size());
+        header = CompressionHeader::read(footer.data(), footer.size());
         dataStart = 0;
     }
+    metrics_.record("File I/O", now_ns() - t0, 0);
     const size_t numChunks = header.chunks.size();
     const size_t per = std::max<size_t>(1, batchBytes_ / (size_t)std::max(1, header.chunkSizeBytes));
-    size_t done = 0;
+    // capacities of a slot: the largest batch in chunks, compressed bytes and decoded bytes (stride * chunks)
+    size_t capK = 0, capComp = 0, capOut = 0;
     for (size_t c0 = 0; c0 < numChunks; c0 += per) {
-        const size_t c1 = std::min(numChunks, c0 + per), K = c1 - c0;
-        t0 = now_ns();
-        std::vector<uint8_t> blob;
-        std::vector<uint64_t> offs(K);
-        std::vector<uint32_t> sizes(K), origs(K);
-        std::vector<uint8_t> lens(K * 256);
-        size_t stride = 16;
-        for (size_t k = 0; k < K; k++) {
-            const ChunkMetadata& c = header.chunks[c0 + k];
-            const size_t beg = dataStart + (size_t)c.compressedOffset;
-            if (beg + c.compressedSize > total)
-                throw IOError("Chunk decompression failed: truncated payload in chunk " + std::to_string(c.chunkIndex));
-            offs[k] = blob.size();
-            sizes[k] = c.compressedSize;
-            origs[k] = c.originalSize;
-            blob.insert(blob.end(), file.begin() + (long)beg, file.begin() + (long)(beg + c.compressedSize));
-            for (int i = 0; i < 256; i++) {
-                if (c.codeLengths[i] < 0 || c.codeLengths[i] > 32) throw IOError("Chunk decompression failed: bad code length table");
-                lens[k * 256 + i] = (uint8_t)c.codeLengths[i];
-            }
-            stride = std::max<size_t>(stride, c.originalSize);
+        const size_t c1 = std::min(numChunks, c0 + per);
+        size_t comp = 0, stride = 16;
+        for (size_t k = c0; k < c1; k++) {
+            comp += header.chunks[k].compressedSize;
+            stride = std::max<size_t>(stride, header.chunks[k].originalSize);
         }
         stride = (stride + 15) & ~(size_t)15;
-        blob.resize(blob.size() + 16, 0);
-        DevBuf dcomp(blob.size()), doff(K * 8), dsize(K * 4), dorig(K * 4), dlen(K * 256), dout(K * stride + 16), dstat(K * 4),
-            derr(K * 8);
-        hip_check(hipMemcpy(dcomp.p, blob.data(), blob.size(), hipMemcpyHostToDevice), "H2D payload");
-        hip_check(hipMemcpy(doff.p, offs.data(), K * 8, hipMemcpyHostToDevice), "H2D");
-        hip_check(hipMemcpy(dsize.p, sizes.data(), K * 4, hipMemcpyHostToDevice), "H2D");
-        hip_check(hipMemcpy(dorig.p, origs.data(), K * 4, hipMemcpyHostToDevice), "H2D");
-        hip_check(hipMemcpy(dlen.p, lens.data(), K * 256, hipMemcpyHostToDevice), "H2D");
-        dcz_check(ctx_, dcz_decompress_blocks(ctx_, dcomp.p, blob.size(), doff.as<uint64_t>(), dsize.as<uint32_t>(),
-                                              dorig.as<uint32_t>(), dlen.as<uint8_t>(), K, stride, dout.p, dstat.as<int32_t>(),
-                                              derr.as<int64_t>(), nullptr),
-                  "dcz_decompress_blocks");
-        hip_check(hipDeviceSynchronize(), "sync");
-        std::vector<int32_t> stat(K);
-        std::vector<int64_t> epos(K);
-        hip_check(hipMemcpy(stat.data(), dstat.p, K * 4, hipMemcpyDeviceToHost), "D2H");
-        hip_check(hipMemcpy(epos.data(), derr.p, K * 8, hipMemcpyDeviceToHost), "D2H");
-        for (size_t k = 0; k < K; k++) {
-            if (stat[k] == DCZ_E_BADSTREAM)  // TableBasedHuffmanDecoder.java:109-111 wrapped by CpuCompressionService.java:469-471
-                throw IOError("Chunk decompression failed: Huffman decode error at position " + std::to_string(epos[k]));
-            if (stat[k] != DCZ_OK) throw IOError(std::string("Chunk decompression failed: ") + dcz_strerror(stat[k]));
-        }
-        // K5 when the decoded chunks are contiguous on the device (all but the last fill the stride) and numerous
-        std::vector<uint8_t> gpu_digests;
-        {
-            bool contiguous = (int64_t)K >= kShaGpuMinChunks;
-            for (size_t k = 0; contiguous && k + 1 < K; k++) contiguous = header.chunks[c0 + k].originalSize == (int64_t)stride;
-            if (contiguous && header.chunks[c0 + K - 1].originalSize <= (int64_t)stride) {
-                const size_t n_dec = (K - 1) * stride + (size_t)header.chunks[c0 + K - 1].originalSize;
-                DevBuf ddig(K * 32);
-                dcz_check(ctx_, dcz_sha256_blocks(ctx_, dout.p, n_dec, stride, ddig.p, nullptr), "dcz_sha256_blocks");
-                hip_check(hipDeviceSynchronize(), "sha256");
-                gpu_digests.resize(K * 32);
-                hip_check(hipMemcpy(gpu_digests.data(), ddig.p, K * 32, hipMemcpyDeviceToHost), "D2H digests");
-            }
-        }
-        std::vector<uint8_t> out(K * stride);
-        hip_check(hipMemcpy(out.data(), dout.p, K * stride, hipMemcpyDeviceToHost), "D2H decoded");
-        metrics_.record("Decoding", now_ns() - t0, (long long)(K * stride));
-        if (gpu_digests.empty()) {  // host threads, one chunk each
-            gpu_digests.resize(K * 32);
-            parallel_chunks((int64_t)K, [&](int64_t k) {
-                sha256(out.data() + (size_t)k * stride, (size_t)header.chunks[c0 + (size_t)k].originalSize, &gpu_digests[(size_t)k * 32]);
-            });
-        }
-        for (size_t k = 0; k < K; k++) {
-            const ChunkMetadata& c = header.chunks[c0 + k];
-            t0 = now_ns();
-            uint8_t d[32];
-            std::memcpy(d, &gpu_digests[k * 32], 32);
-            if (std::memcmp(d, c.sha256, 32) != 0) {  // CpuCompressionService.java:536-550
-                std::ostringstream o;
-                o << "Checksum mismatch in chunk " << c.chunkIndex << ":\n  Expected: " << hex(c.sha256, 32)
-                  << "\n  Actual:   " << hex(d, 32) << "\n  Chunk size: " << c.originalSize
-                  << " bytes\n  Compressed size: " << c.compressedSize << " bytes\n  Compressed offset: "
-                  << c.compressedOffset;
-                throw IOError(o.str());
-            }
-            metrics_.record("Checksum Verification", now_ns() - t0, c.originalSize);
-            sink(out.data() + k * stride, c.originalSize);
-            done++;
-            if (progress) progress((double)done / (double)numChunks);
-        }
+        capK = std::max(capK, c1 - c0);
+        capComp = std::max(capComp, comp);
+        capOut = std::max(capOut, (c1 - c0) * stride);
     }
+    struct Slot {
+        dcz_ctx* ctx = nullptr;
+        bool own_ctx = false;
+        hipStream_t stream = nullptr;
+        uint8_t *hcomp = nullptr, *hout = nullptr, *hmeta = nullptr, *hres = nullptr;  // pinned
+        void *dcomp = nullptr, *doff = nullptr, *dsize = nullptr, *dorig = nullptr, *dlen = nullptr, *dout = nullptr,
+             *dstat = nullptr, *derr = nullptr, *ddig = nullptr;
+        size_t c0 = 0, K = 0, stride = 0;
+        bool busy = false, gpu_sha = false;
+    } slots[2];
+    // pinned metadata of a slot: offs u64[K] | sizes u32[K] | origs u32[K] | lens u8[K*256]; results: status i32[K] |
+    // errpos i64[K] | digests u8[K*32]
+    const size_t metaBytes = capK * (8 + 4 + 4 + 256) + 16, resBytes = capK * (4 + 8 + 32) + 16;
+    auto release = [&]() {
+        for (Slot& sl : slots) {
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+            for (uint8_t* p : {sl.hcomp, sl.hout, sl.hmeta, sl.hres})
+                if (p) (void)hipHostFree(p);
+            for (void* p : {sl.dcomp, sl.doff, sl.dsize, sl.dorig, sl.dlen, sl.dout, sl.dstat, sl.derr, sl.ddig})
+                if (p) (void)hipFree(p);
+            if (sl.own_ctx) dcz_ctx_destroy(sl.ctx);
+            sl = Slot();
+        }
+    };
+    size_t done = 0;
+    const int nslots = (numChunks > per) ? 2 : 1;
+    try {
+        for (int i = 0; i < nslots && numChunks; i++) {
+            Slot& sl = slots[i];
+            if (i == 0) sl.ctx = ctx_;
+            else {
+                if (dcz_ctx_create(device_, &sl.ctx) != DCZ_OK) throw IOError("GPU decompression failed: cannot create a second context");
+                sl.own_ctx = true;
+            }
+            hip_check(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hcomp), capComp + 16, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hout), capOut + 16, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hmeta), metaBytes, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc(reinterpret_cast<void**>(&sl.hres), resBytes, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipMalloc(&sl.dcomp, capComp + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.doff, capK * 8 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dsize, capK * 4 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dorig, capK * 4 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dlen, capK * 256 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dout, capOut + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.dstat, capK * 4 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.derr, capK * 8 + 16), "hipMalloc");
+            hip_check(hipMalloc(&sl.ddig, capK * 32 + 16), "hipMalloc");
+        }
+        // completes a slot's batch in file order: wait, check, verify the checksums, hand the chunks to the sink
+        auto finish = [&](Slot& sl) {
+            if (!sl.busy) return;
+            long long t1 = now_ns();
+            hip_check(hipStreamSynchronize(sl.stream), "sync");
+            const size_t K = sl.K, stride = sl.stride;
+            const int32_t* stat = reinterpret_cast<const int32_t*>(sl.hres);
+            uint8_t* dig = sl.hres + K * 12;
+            for (size_t k = 0; k < K; k++) {
+                int64_t ep;
+                std::memcpy(&ep, sl.hres + K * 4 + k * 8, 8);
+                if (stat[k] == DCZ_E_BADSTREAM)  // TableBasedHuffmanDecoder.java:109-111 wrapped by CpuCompressionService.java:469-471
+                    throw IOError("Chunk decompression failed: Huffman decode error at position " + std::to_string(ep));
+                if (stat[k] != DCZ_OK) throw IOError(std::string("Chunk decompression failed: ") + dcz_strerror(stat[k]));
+            }
+            metrics_.record("Decoding", now_ns() - t1, (long long)(K * stride));
+            t1 = now_ns();
+            if (!sl.gpu_sha) {  // host threads, one chunk each
+                parallel_chunks((int64_t)K, [&](int64_t k) {
+                    sha256(sl.hout + (size_t)k * stride, (size_t)header.chunks[sl.c0 + (size_t)k].originalSize, dig + (size_t)k * 32);
+                });
+            }
+            for (size_t k = 0; k < K; k++) {
+                const ChunkMetadata& c = header.chunks[sl.c0 + k];
+                if (std::memcmp(dig + k * 32, c.sha256, 32) != 0) {  // CpuCompressionService.java:536-550
+                    std::ostringstream o;
+                    o << "Checksum mismatch in chunk " << c.chunkIndex << ":\n  Expected: " << hex(c.sha256, 32)
+                      << "\n  Actual:   " << hex(dig + k * 32, 32) << "\n  Chunk size: " << c.originalSize
+                      << " bytes\n  Compressed size: " << c.compressedSize << " bytes\n  Compressed offset: "
+                      << c.compressedOffset;
+                    throw IOError(o.str());
+                }
+            }
+            metrics_.record("Checksum Verification", now_ns() - t1, (long long)(K * stride));
+            t1 = now_ns();
+            for (size_t k = 0; k < K; k++) {
+                sink(sl.hout + k * stride, header.chunks[sl.c0 + k].originalSize);
+                done++;
+                if (progress) progress((double)done / (double)numChunks);
+            }
+            metrics_.record("File I/O", now_ns() - t1, (long long)(K * stride));
+            sl.busy = false;
+        };
+        int which = 0;
+        for (size_t c0 = 0; c0 < numChunks; c0 += per, which ^= (nslots - 1)) {
+            Slot& sl = slots[which];
+            finish(sl);
+            const size_t c1 = std::min(numChunks, c0 + per), K = c1 - c0;
+            sl.c0 = c0;
+            sl.K = K;
+            t0 = now_ns();
+            uint64_t* offs = reinterpret_cast<uint64_t*>(sl.hmeta);
+            uint32_t* sizes = reinterpret_cast<uint32_t*>(sl.hmeta + K * 8);
+            uint32_t* origs = reinterpret_cast<uint32_t*>(sl.hmeta + K * 12);
+            uint8_t* lens = sl.hmeta + K * 16;
+            size_t stride = 16, comp = 0;
+            bool contiguous_in_file = true;
+            for (size_t k = 0; k < K; k++) {
+                const ChunkMetadata& c = header.chunks[c0 + k];
+                const size_t beg = dataStart + (size_t)c.compressedOffset;
+                if (c.compressedOffset < 0 || beg + c.compressedSize > total)
+                    throw IOError("Chunk decompression failed: truncated payload in chunk " + std::to_string(c.chunkIndex));
+                if (k > 0 && c.compressedOffset != header.chunks[c0 + k - 1].compressedOffset + (int64_t)header.chunks[c0 + k - 1].compressedSize)
+                    contiguous_in_file = false;
+                offs[k] = comp;
+                sizes[k] = c.compressedSize;
+                origs[k] = c.originalSize;
+                comp += c.compressedSize;
+                for (int i = 0; i < 256; i++) {
+                    if (c.codeLengths[i] < 0 || c.codeLengths[i] > 32) throw IOError("Chunk decompression failed: bad code length table");
+                    lens[k * 256 + (size_t)i] = (uint8_t)c.codeLengths[i];
+                }
+                stride = std::max<size_t>(stride, c.originalSize);
+            }
+            stride = (stride + 15) & ~(size_t)15;
+            sl.stride = stride;
+            if (contiguous_in_file) {  // what every writer of this format produces: one read per batch
+                read_at(dataStart + (size_t)header.chunks[c0].compressedOffset, sl.hcomp, comp);
+            } else {
+                for (size_t k = 0; k < K; k++)
+                    read_at(dataStart + (size_t)header.chunks[c0 + k].compressedOffset, sl.hcomp + offs[k], sizes[k]);
+            }
+            std::memset(sl.hcomp + comp, 0, 16);
+            metrics_.record("File I/O", now_ns() - t0, (long long)comp);
+            hip_check(hipMemcpyAsync(sl.dcomp, sl.hcomp, comp + 16, hipMemcpyHostToDevice, sl.stream), "H2D payload");
+            hip_check(hipMemcpyAsync(sl.doff, offs, K * 8, hipMemcpyHostToDevice, sl.stream), "H2D");
+            hip_check(hipMemcpyAsync(sl.dsize, sizes, K * 4, hipMemcpyHostToDevice, sl.stream), "H2D");
+            hip_check(hipMemcpyAsync(sl.dorig, origs, K * 4, hipMemcpyHostToDevice, sl.stream), "H2D");
+            hip_check(hipMemcpyAsync(sl.dlen, lens, K * 256, hipMemcpyHostToDevice, sl.stream), "H2D");
+            dcz_check(sl.ctx, dcz_decompress_blocks(sl.ctx, sl.dcomp, comp + 16, static_cast<uint64_t*>(sl.doff),
+                                                    static_cast<uint32_t*>(sl.dsize), static_cast<uint32_t*>(sl.dorig),
+                                                    static_cast<uint8_t*>(sl.dlen), K, stride, sl.dout,
+                                                    static_cast<int32_t*>(sl.dstat), static_cast<int64_t*>(sl.derr), sl.stream),
+                      "dcz_decompress_blocks");
+            // K5 when the decoded chunks are contiguous on the device (all but the last fill the stride) and numerous
+            bool dense = (int64_t)K >= kShaGpuMinChunks;
+            for (size_t k = 0; dense && k + 1 < K; k++) dense = header.chunks[c0 + k].originalSize == (int64_t)stride;
+            sl.gpu_sha = dense && header.chunks[c0 + K - 1].originalSize <= (int64_t)stride;
+            if (sl.gpu_sha) {
+                const size_t n_dec = (K - 1) * stride + (size_t)header.chunks[c0 + K - 1].originalSize;
+                dcz_check(sl.ctx, dcz_sha256_blocks(sl.ctx, sl.dout, n_dec, stride, sl.ddig, sl.stream), "dcz_sha256_blocks");
+                hip_check(hipMemcpyAsync(sl.hres + K * 12, sl.ddig, K * 32, hipMemcpyDeviceToHost, sl.stream), "D2H digests");
+            }
+            hip_check(hipMemcpyAsync(sl.hres, sl.dstat, K * 4, hipMemcpyDeviceToHost, sl.stream), "D2H");
+            hip_check(hipMemcpyAsync(sl.hres + K * 4, sl.derr, K * 8, hipMemcpyDeviceToHost, sl.stream), "D2H");
+            hip_check(hipMemcpyAsync(sl.hout, sl.dout, K * stride, hipMemcpyDeviceToHost, sl.stream), "D2H decoded");
+            sl.busy = true;
+        }
+        finish(slots[which]);
+        finish(slots[which ^ (nslots - 1)]);
+    } catch (...) {
+        (void)hipDeviceSynchronize();
+        release();
+        throw;
+    }
+    release();
     if (header_out) *header_out = header;
 }
 
