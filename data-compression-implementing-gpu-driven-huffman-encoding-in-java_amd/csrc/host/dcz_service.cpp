@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <atomic>
@@ -250,6 +251,10 @@ static void parallel_chunks(int64_t n, const std::function<void(int64_t)>& fn) {
 HipCompressionService::HipCompressionService(int chunkSizeMB, int device) : device_(device) {
     if (chunkSizeMB <= 0 || chunkSizeMB > 2047) throw std::invalid_argument("chunk size must be 1..2047 MB");
     chunkBytes_ = (int64_t)chunkSizeMB * 1024 * 1024;
+    if (const char* e = std::getenv("DCZ_BATCH_MB")) {  // bytes per pipeline slot (tests use it to force many batches)
+        const long mb = std::atol(e);
+        if (mb > 0) batchBytes_ = (size_t)mb << 20;
+    }
     if (batchBytes_ < (size_t)chunkBytes_) batchBytes_ = (size_t)chunkBytes_;
     if (dcz_device_count() > 0 && dcz_ctx_create(device, &ctx_) != DCZ_OK) ctx_ = nullptr;
 }

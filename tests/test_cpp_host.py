@@ -73,3 +73,32 @@ def test_cli_round_trip_matches_python_mirror_and_oracle(svc, orc, pkg, tmp_path
     # missing input / bad chunk size behave like DataCompCLI.java:38-52
     assert run("c", tmp_path / "nope.bin", tmp_path / "o.dcz").returncode == 1
     assert "Invalid chunk size" in run("c", src, tmp_path / "o.dcz", "abc").stderr
+
+
+@pytest.mark.gpu
+def test_cli_streams_many_batches_through_both_pipeline_slots(svc, orc, pkg, tmp_path, monkeypatch):
+    """DCZ_BATCH_MB=2 with 1 MB chunks: an 11 MB file goes through six batches alternating between the two pipeline
+    slots; the container must be byte-identical to the Python mirror's and round-trip."""
+    data = orc.gen_text(77, 0, 11 * (1 << 20) + 4321)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data.tobytes())
+    monkeypatch.setenv("DCZ_BATCH_MB", "2")
+    r = run("compress", src, tmp_path / "cpp.dcz", 1)
+    assert r.returncode == 0, r.stderr
+    old = svc.chunk_size_bytes
+    try:
+        svc.chunk_size_bytes = 1 << 20
+        svc.compress(str(src), str(tmp_path / "py.dcz"))
+    finally:
+        svc.chunk_size_bytes = old
+    assert (tmp_path / "cpp.dcz").read_bytes() == (tmp_path / "py.dcz").read_bytes()
+    r = run("decompress", tmp_path / "cpp.dcz", tmp_path / "out.bin")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out.bin").read_bytes() == data.tobytes()
+    assert run("verify", tmp_path / "cpp.dcz").returncode == 0
+    # damage in a late batch is still caught, with the reference's message
+    bad = bytearray((tmp_path / "cpp.dcz").read_bytes())
+    bad[len(bad) // 2] ^= 0x10
+    (tmp_path / "bad.dcz").write_bytes(bytes(bad))
+    r = run("decompress", tmp_path / "bad.dcz", tmp_path / "bad.out")
+    assert r.returncode == 1 and ("Checksum mismatch in chunk" in r.stderr or "Huffman decode error at position" in r.stderr)
