@@ -758,3 +758,31 @@ def test_contexts_are_independent_across_threads(pkg, orc):
         t.join()
     assert not errors, errors
     assert len(results) == 6
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_code_build_properties_and_oracle_on_random_histograms(svc, orc, seed):
+    """HuffmanPropertyTest.java:11-78 (jqwik: 256 counts in 0..1000) through dcz_build_codes: codes of one length are
+    distinct, a more frequent symbol never has a longer code, every non-zero count has a code -- and lengths and
+    codewords equal the oracle's PriorityQueue emulation exactly (small ranges make equal weights, hence ties, common)."""
+    rng = np.random.default_rng(9000 + seed)
+    hi = int(rng.choice([2, 5, 50, 1000, 1000000]))
+    h = rng.integers(0, hi + 1, size=256).astype(np.int64)
+    if seed % 7 == 0:
+        h[rng.choice(256, size=int(rng.integers(1, 250)), replace=False)] = 0
+    lens, codes = svc.build_codes(h)
+    olens, ocodes = orc.build_canonical_codes(h)
+    assert (lens == olens).all() and (codes == ocodes).all()
+    nz = np.nonzero(h)[0]
+    assert (lens[nz] > 0).all() and (lens[h == 0] == 0).all()
+    seen = set()
+    for s_ in nz:
+        assert (int(lens[s_]), int(codes[s_])) not in seen
+        seen.add((int(lens[s_]), int(codes[s_])))
+    if nz.size > 1:
+        order = nz[np.argsort(h[nz], kind="stable")]
+        # strictly more frequent => not longer
+        for a, b in zip(order[:-1], order[1:]):
+            if h[b] > h[a]:
+                assert lens[b] <= lens[a]
+        assert sum(2.0 ** -int(l) for l in lens[nz]) <= 1.0 + 1e-12  # prefix-free (Kraft)
