@@ -786,3 +786,29 @@ def test_code_build_properties_and_oracle_on_random_histograms(svc, orc, seed):
             if h[b] > h[a]:
                 assert lens[b] <= lens[a]
         assert sum(2.0 ** -int(l) for l in lens[nz]) <= 1.0 + 1e-12  # prefix-free (Kraft)
+
+
+def test_pipelined_compress_on_a_caller_stream(svc, orc):
+    """>= 2048 blocks take the two-half pipelined path inside dcz_compress_blocks (second HIP stream + events); here it
+    runs on a caller-provided non-default stream, twice back to back, and is followed by the decode on the same stream
+    without any host synchronisation in between."""
+    torch = _torch()
+    bb, K = 16384, 2100
+    data = orc.gen_text(31, 0, bb * K - 777)
+    t = torch.from_numpy(data).cuda()
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        blk = svc.compress_device(t, bb, stream=s.cuda_stream)
+        blk = svc.compress_device(t, bb, out=blk, stream=s.cuda_stream)
+        orig = torch.tensor([min(bb, data.size - k * bb) for k in range(blk.num_chunks)], dtype=torch.int32, device="cuda")
+        out, st, ep = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb,
+                                            stream=s.cuda_stream)
+    s.synchronize()
+    torch.cuda.synchronize()
+    opay, osizes, ooffs, olens = orc.compress_blocks(data, bb)
+    total = int(blk.total.item())
+    assert total == opay.size and (blk.payload[:total].cpu().numpy() == opay).all()
+    assert (blk.comp_size.cpu().numpy().astype(np.uint32) == osizes).all()
+    assert (st.cpu().numpy()[:blk.num_chunks] == 0).all()
+    assert (out.cpu().numpy()[:data.size] == data).all()
