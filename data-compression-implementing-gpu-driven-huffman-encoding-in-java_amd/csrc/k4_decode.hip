@@ -125,6 +125,7 @@ struct DecLds {
     uint8_t symtab[256];
     uint8_t len8[256];
     uint32_t maxlen;
+    uint32_t nomiss;  // complete code with maxlen <= TB: the 2^TB table has no escape entries
     uint32_t err_idx;
     int bad_table;
 };
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         L.lim[0] = 0;
         for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
+        L.nomiss = (mx >= 1u && mx <= (uint32_t)TB && kraft == (1ull << 32)) ? 1u : 0u;
         if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
     }
     __syncthreads();
@@ -579,8 +581,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     }
                     // Lane activity is kept as wave masks in scalar registers (am[s]); the per-lane selects and the
                     // symbol count read them directly (v_cndmask / v_addc with a scalar mask operand).
-                    auto step = [&](auto kc) __attribute__((always_inline)) -> bool {
+                    // nomiss: the table answers every TB-bit pattern (complete code, no codeword longer than TB bits), so
+                    // the escape test and its branch are compiled out of the steps
+                    auto step = [&](auto kc, auto nm) __attribute__((always_inline)) -> bool {
                         constexpr int k = decltype(kc)::value;
+                        constexpr bool NOMISS = decltype(nm)::value;
                         unsigned long long am[NS], any_m = 0;
 #pragma unroll
                         for (int s = 0; s < NS; s++) {
@@ -594,9 +599,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                         for (int s = 0; s < NS; s++) {
                             e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + (window_q(q20[s]) & (uint32_t)(((1 << TB) - 1) << 1)));
                             asm("" : "+v"(e[s]));  // a plain 32-bit value from here on (no 16-bit compare + re-extension)
-                            miss_m |= __builtin_amdgcn_ballot_w64(e[s] == 0u) & am[s];
+                            if constexpr (!NOMISS) miss_m |= __builtin_amdgcn_ballot_w64(e[s] == 0u) & am[s];
                         }
-                        if (miss_m != 0ull) {  // rare: long codeword or no codeword
+                        if (!NOMISS && miss_m != 0ull) {  // rare: long codeword or no codeword
 #pragma unroll
                             for (int s = 0; s < NS; s++) {
                                 bool dead = false;
@@ -625,9 +630,17 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                         }
                         return true;
                     };
-                    [&]<int... Is>(std::integer_sequence<int, Is...>) {
-                        (void)(step(std::integral_constant<int, Is>{}) && ...);
-                    }(std::make_integer_sequence<int, LdsT::PRIV>{});
+                    // (only the instantiation for long codes gets the second copy of the unrolled steps: blocks of the
+                    // medium class practically always have codewords longer than TB bits)
+                    if (LdsT::PRIV <= 48 && L.nomiss) {  // block-uniform
+                        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                            (void)(step(std::integral_constant<int, Is>{}, std::true_type{}) && ...);
+                        }(std::make_integer_sequence<int, LdsT::PRIV>{});
+                    } else {
+                        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                            (void)(step(std::integral_constant<int, Is>{}, std::false_type{}) && ...);
+                        }(std::make_integer_sequence<int, LdsT::PRIV>{});
+                    }
                     any = false;
 #pragma unroll
                     for (int s = 0; s < NS; s++) {
