@@ -85,6 +85,9 @@ constexpr int TB = DCZ_K4_TB;
 #ifndef DCZ_K4_OUTLINE_SLOW
 #define DCZ_K4_OUTLINE_SLOW 1  // parking loop calls the long-code search instead of inlining it in every step
 #endif
+#ifndef DCZ_K4_EXIT_EVERY
+#define DCZ_K4_EXIT_EVERY 1  // measured: 2 is equal, 4 and 8 are 35-45 % SLOWER (the per-step branch keeps the schedule tight)
+#endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
 #endif
@@ -592,7 +595,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                             am[s] = __builtin_amdgcn_ballot_w64(q20[s] > ql20[s]);
                             any_m |= am[s];
                         }
-                        if (any_m == 0ull) return false;
+                        // the early exit is only an optimisation (finished lanes are predicated off): test it every
+                        // DCZ_K4_EXIT_EVERY steps
+                        if constexpr ((k % DCZ_K4_EXIT_EVERY) == 0) {
+                            if (any_m == 0ull) return false;
+                        }
                         uint32_t e[NS];
                         unsigned long long miss_m = 0;
 #pragma unroll
