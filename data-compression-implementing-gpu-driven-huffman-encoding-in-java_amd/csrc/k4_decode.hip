@@ -86,7 +86,7 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4_OUTLINE_SLOW 1  // parking loop calls the long-code search instead of inlining it in every step
 #endif
 #ifndef DCZ_K4_EXIT_EVERY
-#define DCZ_K4_EXIT_EVERY 1  // measured: 2 is equal, 4 and 8 are 35-45 % SLOWER (the per-step branch keeps the schedule tight)
+#define DCZ_K4_EXIT_EVERY 2  // measured over 3 runs each: 2 is ~1.5 % faster than 1; 4 and 8 are 35-45 % SLOWER
 #endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
