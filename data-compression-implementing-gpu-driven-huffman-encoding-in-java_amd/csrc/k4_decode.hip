@@ -45,7 +45,12 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #ifndef DCZ_K4_W
 #define DCZ_K4_W 256
 #endif
-constexpr int TB = DCZ_K4_TB;
+// DCZ_K4_TB: first-level table bits of the long-code and short-code instantiations; DCZ_K4_TBM: of the medium class,
+// whose blocks have many codewords of 12-13 bits (text: 16.5 -> 14.6 ms with 13 bits; the 16 KiB table costs that
+// instantiation no occupancy, it is VGPR-limited to 4 waves/SIMD anyway)
+#ifndef DCZ_K4_TBM
+#define DCZ_K4_TBM 13
+#endif
 // Tuning knobs (measured on MI355X, 8 GiB uniform random, 1 MiB blocks: NS=1/OC=8 KiB/W=256 is fastest -- more
 // resident workgroups hide LDS latency better than in-thread ILP).
 #ifndef DCZ_K4_OC
@@ -95,8 +100,9 @@ constexpr int TB = DCZ_K4_TB;
 #define DCZ_K4S_NS 1
 #endif
 
-template <int W, int NS, int OC, int PV, bool MULTI>
+template <int W, int NS, int OC, int PV, bool MULTI, int TBITS>
 struct DecLds {
+    static constexpr int TB = TBITS;  // index bits of the first-level decode table
     static_assert(W >= 64 && W % 64 == 0, "whole waves only");
     static constexpr int NSUB = W * NS;
     static constexpr int STRIPE = SUB_DW * NS;   // payload dwords per thread
@@ -169,6 +175,7 @@ __device__ __forceinline__ uint32_t add_mask(uint32_t n, unsigned long long m) {
     return r;
 }
 // byte offset into the u16 table of the TB-bit window at npos
+template <int TB>
 __device__ __forceinline__ uint32_t table_off(unsigned long long two, uint32_t npos) {
     return (uint32_t)(two >> ((npos & 31u) + (uint32_t)(32 - TB))) & (uint32_t)(((1 << TB) - 1) << 1);
 }
@@ -181,8 +188,9 @@ __device__ __forceinline__ uint32_t window32(unsigned long long two, uint32_t np
 // length, and everything below the TB+1 range was already answered by the table, so the length of window w is
 // the first l > TB with w < lim[l] (64-bit, left-aligned); four independent LDS reads per step.  No match = no
 // codeword (the reference's "decode error at position i").
-template <int W, int NS, int OC, int PV, bool MULTI>
-__device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV, MULTI>& L, uint32_t win32) {
+template <class LdsT>
+__device__ __forceinline__ uint32_t slow_lookup(const LdsT& L, uint32_t win32) {
+    constexpr int TB = LdsT::TB;
     const uint32_t maxlen = L.maxlen;
     const unsigned long long w = win32;
     for (uint32_t l = TB + 1; l <= maxlen; l += 4) {
@@ -200,6 +208,7 @@ __device__ __forceinline__ uint32_t slow_lookup(const DecLds<W, NS, OC, PV, MULT
 // one inlined copy per step and outgrow the instruction cache.
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
 typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+template <int TB>
 __device__ __attribute__((noinline)) uint32_t slow_lookup_outlined(uint32_t lim_a, uint32_t first_a, uint32_t offs_a,
                                                                    uint32_t symtab_a, uint32_t maxlen, uint32_t win32) {
     lds_cu64* lim = (lds_cu64*)(uintptr_t)lim_a;
@@ -218,8 +227,8 @@ __device__ __attribute__((noinline)) uint32_t slow_lookup_outlined(uint32_t lim_
     return 0;
 }
 
-template <int W, int NS, int OC, int PV, bool MULTI>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, DecLds<W, NS, OC, PV, MULTI>& L, uint32_t& total) {
+template <int W, class LdsT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, LdsT& L, uint32_t& total) {
     const uint32_t inc = wave_inclusive_scan_u32(v);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
@@ -276,7 +285,7 @@ __device__ unsigned long long k4_prof[8];
 // CMASK: the block classes this instantiation decodes (bit 2: >= 6.5 bits per symbol on average, bit 1: at most 72
 // symbols per 32-byte subsequence, bit 0: shorter codes); every launch covers all blocks and each workgroup leaves at
 // once unless its block is of a class it owns.
-template <int W, int NS, int OC, int PV, bool MULTI, int CMASK>
+template <int W, int NS, int OC, int PV, bool MULTI, int CMASK, int TBITS>
 __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAVES : 4) : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
@@ -284,8 +293,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
                                                long long* __restrict__ d_errpos) {
-    using LdsT = DecLds<W, NS, OC, PV, MULTI>;
+    using LdsT = DecLds<W, NS, OC, PV, MULTI, TBITS>;
     __shared__ LdsT L;
+    constexpr int TB = TBITS;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 static_assert(!MULTI || NS == 1, "short-code kernel: one subsequence per thread");
                 while (any) {
                     const unsigned long long two = fetch64(np[0]);
-                    const uint32_t off = table_off(two, np[0]);
+                    const uint32_t off = table_off<TB>(two, np[0]);
                     const bool a = np[0] > nl[0];
                     const bool far = a && (np[0] - nl[0] >= (uint32_t)TB);
                     uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)((far ? mcount_addr : tbl_addr) + off);
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     uint32_t cnt = far ? (e >> 4) : 1u;
                     if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
                         if (a && e == 0) {
-                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            e = slow_lookup(L, window32(two, np[0]));
                             bits = e >> 8;
                             cnt = 1;
                             if (e == 0) {
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     // q20 = descending position + 21: window_q(q20) is the 32 bits that END 12 bits past the
                     // position, so the TB-bit table index sits at bits [TB:1] of the aligned pair and one v_and
                     // yields the byte offset of the u16 entry.
-                    static_assert(TB == 11, "index position in the early window");
+                    constexpr uint32_t QO = 32u - (uint32_t)TB;  // q20 = descending position + QO (21 for the 11-bit table)
                     uint32_t q20[NS], ql20[NS], selv[NS][4];
 #pragma unroll
                     for (int s = 0; s < NS; s++) {
@@ -575,8 +585,8 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #pragma unroll
                             for (int j = 0; j < NR; j++) R[s][j] = 0;
                         }
-                        q20[s] = np[s] + 21u;
-                        ql20[s] = (nl[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[s] + 21u;
+                        q20[s] = np[s] + QO;
+                        ql20[s] = (nl[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : nl[s] + QO;
                         selv[s][0] = need[s] ? 0x03020104u : 0x03020100u;
                         selv[s][1] = need[s] ? 0x03020400u : 0x03020100u;
                         selv[s][2] = need[s] ? 0x03040100u : 0x03020100u;
@@ -614,10 +624,10 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                                 bool dead = false;
                                 if (q20[s] > ql20[s] && e[s] == 0u) {
 #if DCZ_K4_OUTLINE_SLOW
-                                    e[s] = slow_lookup_outlined(lim_addr, first_addr, offs_addr, symtab_addr, L.maxlen,
-                                                                window_q(q20[s] - 20u));
+                                    e[s] = slow_lookup_outlined<TB>(lim_addr, first_addr, offs_addr, symtab_addr, L.maxlen,
+                                                                    window_q(q20[s] - (QO - 1u)));
 #else
-                                    e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window_q(q20[s] - 20u));
+                                    e[s] = slow_lookup(L, window_q(q20[s] - (QO - 1u)));
 #endif
                                     if (e[s] == 0u) {
                                         bad[s] = true;
@@ -651,8 +661,8 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     any = false;
 #pragma unroll
                     for (int s = 0; s < NS; s++) {
-                        np[s] = q20[s] - 21u;
-                        nl[s] = (ql20[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql20[s] - 21u;
+                        np[s] = q20[s] - QO;
+                        nl[s] = (ql20[s] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ql20[s] - QO;
                         any |= np[s] > nl[s];
                     }
                 }
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #pragma unroll
                 for (int s = 0; s < NS; s++)
                     e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
-                                                                                         table_off(two[s], np[s]));
+                                                                                         table_off<TB>(two[s], np[s]));
                 bool miss = false;
 #pragma unroll
                 for (int s = 0; s < NS; s++) miss |= (e[s] == 0 && np[s] > nl[s]);
@@ -673,7 +683,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                         if (e[s] == 0 && np[s] > nl[s]) {
-                            e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two[s], np[s]));
+                            e[s] = slow_lookup(L, window32(two[s], np[s]));
                             if (e[s] == 0) {  // no codeword matches: stop this stream
                                 bad[s] = true;
                                 nl[s] = 0xFFFFFFFFu;
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #pragma unroll
         for (int s = 0; s < NS; s++) tsum += nsym[s];
         uint32_t tw = 0;
-        const uint32_t o = block_exclusive_scan<W, NS, OC, PV, MULTI>(tsum, L, tw);
+        const uint32_t o = block_exclusive_scan<W>(tsum, L, tw);
         const uint32_t remaining = orig - produced;
         {
             uint32_t oo = o;
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 bool any = oi[0] < oe[0];
                 while (any) {
                     const unsigned long long two = fetch64(np[0]);
-                    const uint32_t off = table_off(two, np[0]);
+                    const uint32_t off = table_off<TB>(two, np[0]);
                     const bool a = oi[0] < oe[0];
                     const bool big = a && (oe[0] - oi[0] >= 3u);
                     uint32_t e;
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     uint32_t cnt = big ? (e >> 28) : 1u;
                     if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
                         if (a && e == 0) {
-                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            e = slow_lookup(L, window32(two, np[0]));
                             bits = e >> 8;
                             cnt = 1;
                         }
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                 // short codes: up to 3 symbols per lookup while at least 3 symbols of this chunk are still owed
                 while (any) {
                     const unsigned long long two = fetch64(np[0]);
-                    const uint32_t off = table_off(two, np[0]);  // byte offset of the u16 entry = 2 * index
+                    const uint32_t off = table_off<TB>(two, np[0]);  // byte offset of the u16 entry = 2 * index
                     const bool a = oi[0] < ce[0];
                     const bool big = a && (ce[0] - oi[0] >= 3u);
                     uint32_t e;
@@ -891,7 +901,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     uint32_t cnt = big ? (e >> 28) : 1u;
                     if (__builtin_amdgcn_ballot_w64(a && e == 0) != 0ull) {
                         if (a && e == 0) {
-                            e = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two, np[0]));
+                            e = slow_lookup(L, window32(two, np[0]));
                             bits = e >> 8;
                             cnt = 1;
                         }
@@ -923,14 +933,14 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #pragma unroll
                 for (int s = 0; s < NS; s++)
                     e[s] = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr +
-                                                                                         table_off(two[s], np[s]));
+                                                                                         table_off<TB>(two[s], np[s]));
                 bool miss = false;
 #pragma unroll
                 for (int s = 0; s < NS; s++) miss |= (e[s] == 0 && oi[s] < ce[s]);
                 if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < NS; s++)
-                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup<W, NS, OC, PV, MULTI>(L, window32(two[s], np[s]));
+                        if (e[s] == 0 && oi[s] < ce[s]) e[s] = slow_lookup(L, window32(two[s], np[s]));
                 }
                 any = false;
 #pragma unroll
@@ -1015,27 +1025,27 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     }();
     if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4>), dim3(K), dim3(DCZ_K4_W), 0,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0,
                            s, d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #if DCZ_K4_PRIVM > 0
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2>), dim3(K), dim3(DCZ_K4_W), 0, s,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM>), dim3(K), dim3(DCZ_K4_W), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
                            comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #else
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 3>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
+        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 3, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
                            comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #endif
     } else {
-        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4>), dim3(K), dim3(1024), 0, s,
+        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s,
                            d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #if DCZ_K4S_PRIVM > 0
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2>), dim3(K), dim3(1024), 0, s, d_comp,
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM>), dim3(K), dim3(1024), 0, s, d_comp,
                            comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 1>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #else
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 3>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
+        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 3, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
 #endif
     }
