@@ -271,7 +271,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
 
 #if DCZ_K4_PROF
 // debug build only: cycles per phase, summed over wave 0 of every workgroup (tools/k4prof.py)
-__device__ unsigned long long k4_prof[8];
+__device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds (wave 0 of each workgroup)
 #define PROF_T(i)                                         \
     do {                                                  \
         const unsigned long long t_ = clock64();          \
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     if (orig > 0) prefetch(ventry >> 7);
 
 #if DCZ_K4_PROF
-    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long plast = clock64();
 #endif
     while (produced < orig) {
@@ -520,6 +520,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             }
         }
         uint32_t round = 0;
+#if DCZ_K4_PROF
+        pacc[8]++;
+#endif
         while (true) {
             // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
             // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are
@@ -724,6 +727,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             }
             if (__builtin_amdgcn_ballot_w64(anyneed) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
             round++;
+#if DCZ_K4_PROF
+            pacc[9]++;
+#endif
         }
 
         // ---- offsets, errors ----
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         d_status[b] = status;
         if (d_errpos) d_errpos[b] = errpos;
 #if DCZ_K4_PROF
-        for (int i = 0; i < 8; i++) atomicAdd(&k4_prof[i], pacc[i]);
+        for (int i = 0; i < 12; i++) atomicAdd(&k4_prof[i], pacc[i]);
 #endif
     }
 }
@@ -1057,7 +1063,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 extern "C" void dcz_debug_k4_prof(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::k4_prof), sizeof(dcz::k4_prof));
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         hipMemcpyToSymbol(HIP_SYMBOL(dcz::k4_prof), z, sizeof(z));
     }
 }

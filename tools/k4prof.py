@@ -16,10 +16,11 @@ for name, fill, seed, n, bb in [("rand2g", lib.dczu_fill_java_random, 42, 2 << 3
     blk = svc.compress_device(t, bb)
     K = blk.num_chunks
     orig = torch.full((K,), bb, dtype=torch.int32, device="cuda")
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     prof(buf, 1)
     out, st, ep = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb)
     torch.cuda.synchronize()
     prof(buf, 1)
-    v = np.array(list(buf), dtype=np.float64)
+    v = np.array(list(buf)[:8], dtype=np.float64)
+    print("   windows %d, self-sync rounds per window %.2f" % (buf[8], buf[9] / max(1, buf[8])))
     print(name, "ok", bool(torch.equal(out[:n], t)), " ".join("%s %.1f%%" % (nm, 100 * x / v.sum()) for nm, x in zip(names, v)))
