@@ -93,6 +93,9 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #ifndef DCZ_K4_EXIT_EVERY
 #define DCZ_K4_EXIT_EVERY 2  // measured over 3 runs each: 2 is ~1.5 % faster than 1; 4 and 8 are 35-45 % SLOWER
 #endif
+#ifndef DCZ_K4_GROUP
+#define DCZ_K4_GROUP 1
+#endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
 #endif
@@ -154,6 +157,14 @@ __device__ __forceinline__ unsigned long long fetch64(uint32_t npos) {
 __device__ __forceinline__ uint32_t window_q(uint32_t q) {
     lds_cu32* p = (lds_cu32*)(uintptr_t)((q >> 3) & ~3u);
     return __builtin_amdgcn_alignbit(p[1], p[0], q);
+}
+// w << ((e >> 8) & 0xFF) in one VALU op
+__device__ __forceinline__ uint32_t shl_byte1(uint32_t w, uint32_t e) {
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+        : "=v"(r)
+        : "v"(e), "v"(w));
+    return r;
 }
 // a - ((e >> 8) & 0xFF) in one VALU op (SDWA byte select)
 __device__ __forceinline__ uint32_t sub_byte1(uint32_t a, uint32_t e) {
@@ -652,6 +663,33 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                     };
                     // (only the instantiation for long codes gets the second copy of the unrolled steps: blocks of the
                     // medium class practically always have codewords longer than TB bits)
+#if DCZ_K4_GROUP
+                    // Total table and no codeword longer than 8 bits: one 32-bit window holds four whole codewords, so
+                    // the window is fetched once per four symbols and shifted in a register in between -- three of
+                    // four steps have one LDS round trip (the table) instead of two on their dependency chain.
+                    if (NS == 1 && LdsT::PRIV <= 48 && L.nomiss && L.maxlen <= 8u) {  // block-uniform
+                        auto quad = [&](auto kc) __attribute__((always_inline)) -> bool {
+                            constexpr int k = 4 * decltype(kc)::value;
+                            if (__builtin_amdgcn_ballot_w64(q20[0] > ql20[0]) == 0ull) return false;
+                            uint32_t w = window_q(q20[0] - (QO - 1u));  // the 32 bits at the position
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const unsigned long long am = __builtin_amdgcn_ballot_w64(q20[0] > ql20[0]);
+                                uint32_t e = *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(tbl_addr + ((w >> (31 - TB)) & (uint32_t)(((1 << TB) - 1) << 1)));
+                                asm("" : "+v"(e));
+                                e = select_mask(e, am);
+                                R[0][(k + j) >> 2] = __builtin_amdgcn_perm(e, R[0][(k + j) >> 2], selv[0][(k + j) & 3]);
+                                q20[0] = sub_byte1(q20[0], e);
+                                nsym[0] = add_mask(nsym[0], am);
+                                if (j < 3) w = shl_byte1(w, e);
+                            }
+                            return true;
+                        };
+                        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                            (void)(quad(std::integral_constant<int, Is>{}) && ...);
+                        }(std::make_integer_sequence<int, LdsT::PRIV / 4>{});
+                    } else
+#endif
                     if (LdsT::PRIV <= 48 && L.nomiss) {  // block-uniform
                         [&]<int... Is>(std::integer_sequence<int, Is...>) {
                             (void)(step(std::integral_constant<int, Is>{}, std::true_type{}) && ...);
