@@ -661,13 +661,13 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                         }
                         return true;
                     };
-                    // (only the instantiation for long codes gets the second copy of the unrolled steps: blocks of the
+                    // (only the instantiations for long codes get the second copy of the unrolled steps: blocks of the
                     // medium class practically always have codewords longer than TB bits)
 #if DCZ_K4_GROUP
                     // Total table and no codeword longer than 8 bits: one 32-bit window holds four whole codewords, so
                     // the window is fetched once per four symbols and shifted in a register in between -- three of
                     // four steps have one LDS round trip (the table) instead of two on their dependency chain.
-                    if (NS == 1 && LdsT::PRIV <= 48 && L.nomiss && L.maxlen <= 8u) {  // block-uniform
+                    if (NS == 1 && LdsT::PRIV <= 64 && L.nomiss && L.maxlen <= 8u) {  // block-uniform
                         auto quad = [&](auto kc) __attribute__((always_inline)) -> bool {
                             constexpr int k = 4 * decltype(kc)::value;
                             if (__builtin_amdgcn_ballot_w64(q20[0] > ql20[0]) == 0ull) return false;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
                         }(std::make_integer_sequence<int, LdsT::PRIV / 4>{});
                     } else
 #endif
-                    if (LdsT::PRIV <= 48 && L.nomiss) {  // block-uniform
+                    if (LdsT::PRIV <= 64 && L.nomiss) {  // block-uniform
                         [&]<int... Is>(std::integer_sequence<int, Is...>) {
                             (void)(step(std::integral_constant<int, Is>{}, std::true_type{}) && ...);
                         }(std::make_integer_sequence<int, LdsT::PRIV>{});
