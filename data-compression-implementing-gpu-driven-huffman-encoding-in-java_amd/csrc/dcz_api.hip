@@ -26,6 +26,8 @@ struct dcz_ctx {
     uint32_t* code = nullptr;
     uint8_t* maxlen = nullptr;
     size_t cap_nseg = 0, cap_K = 0;
+    uint8_t* dslow = nullptr;        // decoder: blocks handed to the exact-entry launch
+    size_t cap_slow = 0;
     // staging for the host-pointer API (grow-only)
     uint8_t* st_in = nullptr;
     size_t st_in_cap = 0;
@@ -257,6 +259,7 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     (void)hipFree(c->seg_bitoff);
     (void)hipFree(c->code);
     (void)hipFree(c->maxlen);
+    (void)hipFree(c->dslow);
     (void)hipFree(c->st_in);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
@@ -384,10 +387,18 @@ int dcz_decompress_blocks(dcz_ctx* c, const void* d_comp, size_t comp_bytes, con
     if (!d_out) return DCZ_E_INVALID;
     DeviceGuard dg(c->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (K > c->cap_slow) {  // one byte per block: "did not self-synchronise" (grow-only workspace of the decoder)
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->dslow) (void)hipFree(c->dslow);
+        c->dslow = nullptr;
+        c->cap_slow = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dslow), K + 256));
+        c->cap_slow = K + 256;
+    }
     {
         KernelTimer t(c, s, DCZ_K_DECODE);
         launch_decode(static_cast<const uint8_t*>(d_comp), comp_bytes, d_comp_off, d_comp_size, d_orig_size, d_len,
-                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, s);
+                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, c->dslow, s);
     }
     return launch_check(c);
 }

@@ -38,7 +38,7 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
 // K4: decode.
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                   int32_t* d_status, int64_t* d_errpos, hipStream_t s);
+                   int32_t* d_status, int64_t* d_errpos, uint8_t* d_slow /* K bytes of workspace */, hipStream_t s);
 
 // K5: SHA-256 of every block -> digests[K][32].
 void launch_sha256(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t K, uint8_t* d_digests, hipStream_t s);

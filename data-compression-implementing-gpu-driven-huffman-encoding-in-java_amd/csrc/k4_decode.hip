@@ -96,6 +96,13 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #ifndef DCZ_K4_GROUP
 #define DCZ_K4_GROUP 1
 #endif
+#ifndef DCZ_K4_EXACT
+#define DCZ_K4_EXACT 1        // exact-entry procedure for windows that do not self-synchronise
+#endif
+#ifndef DCZ_K4_EXACT_AFTER
+#define DCZ_K4_EXACT_AFTER 12 // decode rounds a window may take before its block is handed to the exact-entry launch
+                              // (measured: a block that needs ~7 rounds is still faster on the regular path)
+#endif
 #ifndef DCZ_K4_OCX
 #define DCZ_K4_OCX 512   // tile bytes beyond OC: a window of 8-bit codes (W*32 symbols) plus a carried tail fits one flush
 #endif
@@ -280,6 +287,90 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long 
                // so that nothing waits for the load where it is issued
 }
 
+// ---- exact entries for windows that do not self-synchronise ------------------------------------------------------
+// Streams of (nearly) equal-length codewords whose length does not divide the subsequence keep a wrong phase for ever, so
+// the fixed point of phase A advances one subsequence per round.  After DCZ_K4_EXACT_AFTER rounds a window switches to
+// this procedure (and the rest of its block starts with it): every thread computes, for EVERY possible entry offset e of
+// its subsequence (e < maxlen), the offset F[e] at which the parse from e leaves the subsequence -- descending in e, so
+// that F[e] = F[e + len(e)] is a table read whenever the first codeword stays below maxlen, and only one parse per
+// distinct track is decoded to the end -- then ONE lane walks the window: entry(q+1) = F_q[entry(q)].  The true entries
+// go to L.exits[], the caller decodes once more from them.  F lives in the (unused in phase A) output tile, 32 bytes per
+// subsequence from byte 64 on (the first 16 bytes of the tile hold the carried tail), and is zeroed again afterwards.
+// All arguments that are addresses are LDS byte addresses.  Must be called by every thread of the workgroup.
+template <int TB, int W>
+__device__ __attribute__((noinline)) void k4_exact_entries(uint32_t ftab_a, uint32_t exits_a, uint32_t tbl_a, uint32_t lim_a,
+                                                           uint32_t first_a, uint32_t offs_a, uint32_t symtab_a,
+                                                           uint32_t maxlen, uint32_t nbase, uint32_t g0, uint32_t tid,
+                                                           bool beyond) {
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    constexpr uint32_t QO = 32u - (uint32_t)TB;
+    lds_u8* const frow = (lds_u8*)(uintptr_t)(ftab_a + 32u * tid);
+    const uint32_t emax = maxlen < 32u ? (maxlen ? maxlen : 1u) : 32u;
+    const uint32_t ql = nbase - (uint32_t)SUB_BITS + QO;  // limit of the subsequence in the q20 form
+    // parse from stripe bit `start` (the first codeword is decoded by the caller when stop_below > 0): returns the exit
+    auto run = [&](uint32_t start, uint32_t stop_below, bool active, uint32_t& landed) -> uint32_t {
+        uint32_t q = active ? nbase - start + QO : ql;  // inactive lanes are past their limit from the beginning
+        bool first = true;
+        landed = 0xFFFFFFFFu;
+        while (true) {
+            unsigned long long am = __builtin_amdgcn_ballot_w64(q > ql);
+            if (am == 0ull) break;
+            uint32_t e = *(lds_u16*)(uintptr_t)(tbl_a + (window_q(q) & (uint32_t)(((1 << TB) - 1) << 1)));
+            asm("" : "+v"(e));
+            if ((__builtin_amdgcn_ballot_w64(e == 0u) & am) != 0ull) {
+                bool dead = false;
+                if (q > ql && e == 0u) {
+                    e = slow_lookup_outlined<TB>(lim_a, first_a, offs_a, symtab_a, maxlen, window_q(q - (QO - 1u)));
+                    if (e == 0u) {  // no codeword on this parse: it ends here (any exit will do, the true chain never
+                        q = ql;     // follows it unless the stream is damaged, which the final decode reports)
+                        dead = true;
+                    }
+                }
+                am &= ~__builtin_amdgcn_ballot_w64(dead);
+            }
+            e = select_mask(e, am);
+            q = sub_byte1(q, e);
+            if (first) {  // position after the first codeword; a lane whose parse lands below stop_below is done
+                first = false;
+                const uint32_t pos = nbase + QO - q;
+                if (active && pos < stop_below) {
+                    landed = pos;
+                    q = ql;
+                }
+            }
+        }
+        return (nbase + QO - q) - (uint32_t)SUB_BITS;
+    };
+    for (uint32_t e = emax; e-- > 0u;) {  // descending: F[e + len] is known when it is needed
+        uint32_t landed;
+        const uint32_t x = run(e, emax, !beyond, landed);
+        if (!beyond) frow[e] = (uint8_t)((landed != 0xFFFFFFFFu) ? (uint32_t)frow[landed] : (x & 31u));
+    }
+    uint32_t x0 = 0;
+    {   // the window's first subsequence enters at g0 (up to 127 bits in): its exit is decoded directly
+        uint32_t landed;
+        x0 = run(g0, 0u, tid == 0u && !beyond, landed) & 31u;
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        __attribute__((address_space(3))) uint16_t* const ex = (__attribute__((address_space(3))) uint16_t*)(uintptr_t)exits_a;
+        uint32_t e = x0;
+        ex[0] = (uint16_t)e;
+        for (uint32_t q = 1; q < (uint32_t)W; q++) {
+            e = (uint32_t)((lds_u8*)(uintptr_t)(ftab_a + 32u * q))[e & 31u] & 31u;
+            ex[q] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+    {
+        __attribute__((address_space(3))) uint32_t* const z = (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(ftab_a + 32u * tid);
+#pragma unroll
+        for (int i = 0; i < 8; i++) z[i] = 0u;
+    }
+    __syncthreads();
+}
+
 #if DCZ_K4_PROF
 // debug build only: cycles per phase, summed over wave 0 of every workgroup (tools/k4prof.py)
 __device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds (wave 0 of each workgroup)
@@ -296,20 +387,32 @@ __device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds
 // CMASK: the block classes this instantiation decodes (bit 2: >= 6.5 bits per symbol on average, bit 1: at most 72
 // symbols per 32-byte subsequence, bit 0: shorter codes); every launch covers all blocks and each workgroup leaves at
 // once unless its block is of a class it owns.
-template <int W, int NS, int OC, int PV, bool MULTI, int CMASK, int TBITS>
+// MODE 0: the regular decoder (leaves at once if its block is flagged in d_slow).
+// MODE 2: the probe, launched first: table build and phase A of the block's FIRST window only; a block whose window is not
+//         synchronised after DCZ_K4_EXACT_AFTER rounds is flagged in d_slow.
+// MODE 1: the exact-entry decoder, launched last: decodes the flagged blocks with k4_exact_entries in every window.
+// Keeping the probe's give-up test and the exact-entry call out of the regular kernels keeps their register allocation
+// what it was (with either inside, the uniform case lost 9-14 %).
+template <int W, int NS, int OC, int PV, bool MULTI, int CMASK, int TBITS, int MODE>
 __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAVES : 4) : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
                                                const uint32_t* __restrict__ d_orig_size,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
-                                               long long* __restrict__ d_errpos) {
+                                               long long* __restrict__ d_errpos, uint8_t* __restrict__ d_slow) {
     using LdsT = DecLds<W, NS, OC, PV, MULTI, TBITS>;
     __shared__ LdsT L;
     constexpr int TB = TBITS;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
+    constexpr bool XM = MODE == 1;
+    if constexpr (MODE == 1) {
+        if (d_slow[b] == 0) return;  // workgroup-uniform: only the blocks the probe flagged
+    } else if constexpr (MODE == 0 && DCZ_K4_EXACT && !MULTI) {
+        if (d_slow[b] != 0) return;  // the exact-entry launch decodes this block
+    }
 
     // ---- block geometry ----
     const uint32_t orig = d_orig_size[b];
@@ -433,6 +536,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     // overflow and are decoded twice anyway.
     const bool park = LdsT::PRIV > 0 &&
                       (unsigned long long)orig * 128ull <= (unsigned long long)csize * 3ull * (unsigned long long)LdsT::PRIV;
+    bool slow_block = XM;                     // exact-entry instantiation: every window starts from exact entries
     unsigned long long ventry = 8ull * skew;  // virtual bit of the next codeword boundary
     uint32_t produced = 0;                    // symbols decoded so far
     uint32_t gpos = 0;                        // block-relative output offset of tile byte 0 (multiple of 16)
@@ -534,6 +638,24 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #if DCZ_K4_PROF
         pacc[8]++;
 #endif
+        bool exact_done = false;
+        auto take_exact_entries = [&]() __attribute__((always_inline)) {
+            if constexpr (XM) {
+                static_assert(!MULTI && NS == 1, "exact-entry instantiation");
+                static_assert(sizeof(L.outbuf) >= 64 + 32 * (size_t)W, "entry-to-exit tables fit the output tile");
+                const uint32_t ftab_a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.outbuf[16]));
+                const uint32_t exits_a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.exits[0]));
+                k4_exact_entries<TB, W>(ftab_a, exits_a, tbl_addr, lim_addr, first_addr, offs_addr, symtab_addr, L.maxlen,
+                                        nbase, g0, (uint32_t)tid, beyond[0]);
+                const uint32_t ng = (tid == 0) ? g0 : (uint32_t)L.exits[tid - 1];
+                // (need[0] still set = the lane's registers belong to an older entry than g[0])
+                need[0] = (need[0] || ng != g[0] || round == 0u) && !beyond[0];
+                g[0] = ng;
+                exact_done = true;
+                slow_block = true;
+            }
+        };
+        if (slow_block) take_exact_entries();  // workgroup-uniform: an earlier window of this block did not converge
         while (true) {
             // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
             // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are
@@ -753,6 +875,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             if (tid == 0) L.flag[(round + 1u) % 3u] = 0;
             __syncthreads();
             PROF_T(2);
+            if (exact_done) break;  // the entries were exact: this decode was the final one
             if (round > 0u && L.flag[round % 3u] == 0u) break;
             bool anyneed = false;
 #pragma unroll
@@ -768,7 +891,15 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 #if DCZ_K4_PROF
             pacc[9]++;
 #endif
+            if constexpr (MODE == 2) {
+                if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
+                    if (tid == 0) d_slow[b] = 1;
+                    return;
+                }
+            }
         }
+
+        if constexpr (MODE == 2) return;  // the probe only wanted to know whether the first window synchronises
 
         // ---- offsets, errors ----
         uint32_t tsum = 0;
@@ -1058,41 +1189,46 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                   int32_t* d_status, int64_t* d_errpos, hipStream_t s) {
+                   int32_t* d_status, int64_t* d_errpos, uint8_t* d_slow, hipStream_t s) {
     if (K == 0) return;
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
+    (void)hipMemsetAsync(d_slow, 0, K, s);
     // Below this many blocks one 1024-thread workgroup per block keeps more waves resident than 256-thread ones.
     static const uint32_t few_below = [] {
         const char* e = getenv("DCZ_K4_FEW_BLOCKS_BELOW");  // tuning knob
         return e ? (uint32_t)atoi(e) : 1024u;
     }();
+#define DCZ_K4_LAUNCH(WW, NSS, OCC, PVV, MM, CC, TT, XX)                                                                \
+    hipLaunchKernelGGL((k4_decode<WW, NSS, OCC, PVV, MM, CC, TT, XX>), dim3(K), dim3(WW), 0, s, d_comp, comp_bytes, off, \
+                       d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, d_slow)
     if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0,
-                           s, d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-#if DCZ_K4_PRIVM > 0
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM>), dim3(K), dim3(DCZ_K4_W), 0, s,
-                           d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
-                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-#else
-        hipLaunchKernelGGL((k4_decode<DCZ_K4_W, 1, DCZ_K4M_OC, 0, true, 3, DCZ_K4_TB>), dim3(K), dim3(DCZ_K4_W), 0, s, d_comp,
-                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#if DCZ_K4_EXACT
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 2);
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 2);
+#endif
+        DCZ_K4_LAUNCH(DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 0);
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 0);
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TB, 0);
+#if DCZ_K4_EXACT
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 1);
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 1);
 #endif
     } else {
-        hipLaunchKernelGGL((k4_decode<1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s,
-                           d_comp, comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-#if DCZ_K4S_PRIVM > 0
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM>), dim3(K), dim3(1024), 0, s, d_comp,
-                           comp_bytes, off, d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
-                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
-#else
-        hipLaunchKernelGGL((k4_decode<1024, 1, DCZ_K4S_OC, 0, true, 3, DCZ_K4_TB>), dim3(K), dim3(1024), 0, s, d_comp, comp_bytes, off,
-                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep);
+#if DCZ_K4_EXACT
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 2);
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 2);
+#endif
+        DCZ_K4_LAUNCH(1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 0);
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 0);
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TB, 0);
+#if DCZ_K4_EXACT
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 1);
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 1);
 #endif
     }
+#undef DCZ_K4_LAUNCH
 }
 
 }  // namespace dcz
