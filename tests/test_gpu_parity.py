@@ -812,3 +812,78 @@ def test_pipelined_compress_on_a_caller_stream(svc, orc):
     assert (blk.comp_size.cpu().numpy().astype(np.uint32) == osizes).all()
     assert (st.cpu().numpy()[:blk.num_chunks] == 0).all()
     assert (out.cpu().numpy()[:data.size] == data).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Streams that do not self-synchronise: (nearly) fixed-length codes whose length does not divide the 256-bit
+# subsequence keep a wrong phase for ever.  A probe launch finds such blocks and the exact-entry instantiations decode
+# them (k4_exact_entries).  Parity with the oracle in both launch shapes, with ragged tails and damaged streams.
+def _fixed_length_like(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "sym64":      # 64 equiprobable symbols: 6-bit codes (base64-like)
+        return rng.integers(0, 64, size=n).astype(np.uint8) + 32
+    if kind == "sym128":     # 128 equiprobable symbols + rare others: 7-bit codes, one 8-bit code, long tail
+        p = np.r_[np.full(128, 1.0), np.full(128, 2e-4)]
+    elif kind == "ripple":   # near-uniform bytes: 7/8/9-bit codes mixed
+        p = 1.0 + 0.3 * np.sin(np.arange(256))
+    elif kind == "sym3":     # 3 equiprobable symbols: lengths 1/2/2
+        return (rng.integers(0, 3, size=n) * 7).astype(np.uint8)
+    elif kind == "sym32":    # 5-bit codes
+        return (rng.integers(0, 32, size=n) * 3).astype(np.uint8)
+    else:
+        raise ValueError(kind)
+    return rng.choice(256, size=n, p=p / p.sum()).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind", ["sym64", "sym128", "ripple", "sym3", "sym32"])
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
+def test_parity_streams_that_do_not_self_synchronise(svc, orc, kind, shape):
+    if shape == "many_blocks":
+        bb, n = 65536, 1060 * 65536 + 777
+    else:
+        bb, n = 1 << 20, 9 * (1 << 20) + 54321
+    data = _fixed_length_like(kind, n, seed=len(kind) * 17 + len(shape))
+    assert_parity(svc, orc, data, bb)
+
+
+def test_exact_entry_decoder_reports_damage_like_the_reference(pkg, svc, orc):
+    """Incomplete table of equal-length codewords (so the stream does not self-synchronise and goes through the
+    exact-entry decoder) with bit flips: status, error position and bytes per block against the oracle decoder."""
+    torch = _torch()
+    rng = np.random.default_rng(23)
+    lens = np.zeros(256, np.int32)
+    syms = rng.choice(256, size=100, replace=False)
+    lens[syms] = 7  # 100 of the 128 seven-bit patterns are codewords
+    codes, _ = orc.canonical_codes(lens)
+    K, nsym = 1030, 40000
+    pays, want = [], []
+    for k in range(K):
+        data = rng.choice(syms, size=nsym).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        pay = pay.copy()
+        if k % 4 == 1:
+            i = int(rng.integers(0, pay.size))
+            pay[i] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        try:
+            want.append((0, 0, orc.decode_block(pay, lens, nsym)))
+        except orc.DecodeError as e:
+            want.append((pkg.native.DCZ_E_BADSTREAM, e.position, None))
+        pays.append(pay)
+    sizes = np.array([p.size for p in pays], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
+    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
+    stride = (nsym + 15) & ~15
+    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                        torch.full((K,), nsym, dtype=torch.int32, device="cuda"),
+                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
+    torch.cuda.synchronize()
+    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
+    nerr = 0
+    for k, (wst, wpos, wdata) in enumerate(want):
+        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
+        if wst:
+            nerr += 1
+            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
+        else:
+            assert (out[k * stride:k * stride + nsym] == wdata).all(), "block %d decodes differently" % k
+    assert nerr > 20
