@@ -145,6 +145,7 @@ struct DecLds {
     uint8_t len8[256];
     uint32_t maxlen;
     uint32_t nomiss;  // complete code with maxlen <= TB: the 2^TB table has no escape entries
+    uint32_t in_phase;  // one code length that divides SUB_BITS: entry offsets are known without decoding
     uint32_t err_idx;
     int bad_table;
 };
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         L.maxlen = mx;
         L.nomiss = (mx >= 1u && mx <= (uint32_t)TB && kraft == (1ull << 32)) ? 1u : 0u;
         if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
+        // every codeword has the same length and that length divides the subsequence: always in phase
+        L.in_phase = (mx >= 1u && L.cnt[mx] > 0u && kraft == ((unsigned long long)L.cnt[mx] << (32u - mx)) &&
+                      ((uint32_t)SUB_BITS % mx) == 0u) ? 1u : 0u;
     }
     __syncthreads();
     if (L.bad_table) {
@@ -465,6 +469,9 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             if (d_errpos) d_errpos[b] = 0;
         }
         return;
+    }
+    if constexpr (MODE == 2) {
+        if (L.in_phase) return;  // the probe has nothing to find out (e.g. 256 symbols of 8 bits)
     }
     for (int sy = tid; sy < 256; sy += W) {
         const uint32_t l = L.len8[sy];
