@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libdczhip.so")
-SOURCES = ["dcz_api.hip", "k1_histogram.hip", "k2_codebuild.hip", "k3_encode.hip", "k4_decode.hip", "k5_sha256.hip", "gen.hip"]
+SOURCES = ["dcz_api.hip", "k1_histogram.hip", "k2_codebuild.hip", "k3_encode.hip", "k4_decode.hip", "k4_fixed.hip", "k5_sha256.hip", "gen.hip"]
 HEADERS = ["dcz_internal.h", os.path.join("..", "..", "include", "dcz.h")]
 
 
@@ -40,20 +40,42 @@ def build_host(force=False, verbose=False):
     return CLI
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), so=None, objdir=None):
+    """Compile every .hip source to an object (in parallel, only the stale ones) and link libdczhip.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    so = so or SO
+    main = so == SO
+    if main and not force and not _stale():
         build_host(False, verbose)
-        return SO
+        return so
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-o", SO] + [os.path.join(CSRC, f) for f in SOURCES]
+    objdir = objdir or os.path.join(HERE, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"] + list(extra_flags)
+
+    def compile_one(f):
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    build_host(True, verbose)
-    return SO
+    if main:
+        build_host(True, verbose)
+    return so
 
 
 if __name__ == "__main__":

@@ -26,8 +26,8 @@ struct dcz_ctx {
     uint32_t* code = nullptr;
     uint8_t* maxlen = nullptr;
     size_t cap_nseg = 0, cap_K = 0;
-    uint8_t* dslow = nullptr;        // decoder: blocks handed to the exact-entry launch
-    size_t cap_slow = 0;
+    uint8_t* dws = nullptr;          // decoder workspace (DecodeWs: class bytes, work list of fixed-length blocks)
+    size_t cap_dws_K = 0;            // blocks it holds
     // staging for the host-pointer API (grow-only)
     uint8_t* st_in = nullptr;
     size_t st_in_cap = 0;
@@ -140,6 +140,23 @@ int grow(dcz_ctx* c, T** p, size_t* cap, size_t need_elems) {
     const size_t elems = need_elems + need_elems / 8 + 64;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), elems * sizeof(T)));
     *cap = elems;
+    return DCZ_OK;
+}
+
+// Decoder workspace for K blocks.  Growing it frees the old buffer, which the stream may still be using: callers that
+// must not synchronise (hipGraph capture, pipelines) size it up front with dcz_ctx_reserve.
+int reserve_decode(dcz_ctx* c, size_t K, hipStream_t s) {
+    if (K <= c->cap_dws_K && c->dws) return DCZ_OK;
+    if (c->dws) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->dws));
+    }
+    c->dws = nullptr;
+    c->cap_dws_K = 0;
+    const size_t nk = K + K / 8 + 256;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dws), decode_ws_bytes(nk)));
+    c->cap_dws_K = nk;
     return DCZ_OK;
 }
 
@@ -259,7 +276,7 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     (void)hipFree(c->seg_bitoff);
     (void)hipFree(c->code);
     (void)hipFree(c->maxlen);
-    (void)hipFree(c->dslow);
+    (void)hipFree(c->dws);
     (void)hipFree(c->st_in);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
@@ -270,6 +287,8 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+void* dcz_ctx_stream(dcz_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
 const char* dcz_strerror(int status) {
     switch (status) {
@@ -293,7 +312,9 @@ int dcz_ctx_reserve(dcz_ctx* c, size_t n, size_t block_bytes) {
     int r = geometry(n, block_bytes, &g);
     if (r != DCZ_OK) return r;
     DeviceGuard dg(c->device);
-    return reserve(c, g);
+    r = reserve(c, g);
+    if (r != DCZ_OK) return r;
+    return reserve_decode(c, g.K, c->stream);
 }
 
 int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_bytes, void* d_out, size_t out_cap,
@@ -387,18 +408,13 @@ int dcz_decompress_blocks(dcz_ctx* c, const void* d_comp, size_t comp_bytes, con
     if (!d_out) return DCZ_E_INVALID;
     DeviceGuard dg(c->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    if (K > c->cap_slow) {  // one byte per block: "did not self-synchronise" (grow-only workspace of the decoder)
-        HIPCHK(c, hipStreamSynchronize(s));
-        if (c->dslow) (void)hipFree(c->dslow);
-        c->dslow = nullptr;
-        c->cap_slow = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dslow), K + 256));
-        c->cap_slow = K + 256;
-    }
+    int r = reserve_decode(c, K, s);  // no-op (no synchronisation, no allocation) after dcz_ctx_reserve
+    if (r != DCZ_OK) return r;
     {
         KernelTimer t(c, s, DCZ_K_DECODE);
         launch_decode(static_cast<const uint8_t*>(d_comp), comp_bytes, d_comp_off, d_comp_size, d_orig_size, d_len,
-                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, c->dslow, s);
+                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos,
+                      decode_ws_at(c->dws, c->cap_dws_K), s);
     }
     return launch_check(c);
 }

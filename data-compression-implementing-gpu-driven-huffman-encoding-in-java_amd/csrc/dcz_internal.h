@@ -35,10 +35,25 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
                    const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
                    const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s);
 
-// K4: decode.
+// K4: decode.  Workspace of one decode call (device memory, see decode_ws_bytes).
+struct DecodeWs {
+    uint8_t* cls;  // K x u8: class byte of every block (k4_classify, then the probe launch)
+};
+inline size_t decode_ws_bytes(size_t K) { return K + 64; }
+inline DecodeWs decode_ws_at(void* base, size_t K) {
+    (void)K;
+    return DecodeWs{static_cast<uint8_t*>(base)};
+}
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                   int32_t* d_status, int64_t* d_errpos, uint8_t* d_slow /* K bytes of workspace */, hipStream_t s);
+                   int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, hipStream_t s);
+// k4_fixed.hip: class byte per block + bounds check of the footer fields; analytic decode of fixed-length complete codes
+void launch_classify(const uint8_t* d_len, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                     const uint32_t* d_orig_size, size_t comp_bytes, size_t out_stride, uint32_t K, const DecodeWs& ws,
+                     int32_t* d_status, int64_t* d_errpos, hipStream_t s);
+void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                         const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
+                         const DecodeWs& ws, hipStream_t s);
 
 // K5: SHA-256 of every block -> digests[K][32].
 void launch_sha256(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t K, uint8_t* d_digests, hipStream_t s);
@@ -49,6 +64,8 @@ void launch_fill_text(uint8_t* d, size_t n, uint64_t seed, uint64_t start, hipSt
 void launch_fill_lowentropy(uint8_t* d, size_t n, uint64_t seed, uint64_t start, hipStream_t s);
 
 #if defined(__HIPCC__)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: what the non-temporal builtins take
+
 // ---- device helpers --------------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -75,6 +92,31 @@ __device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v) {
 }
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// Load one 16-byte chunk of the payload (virtual byte vb), zero outside [vlo, vhi).
+__device__ __forceinline__ uint4 load_chunk16(const uint8_t* vbase, unsigned long long vb, unsigned long long vlo,
+                                            unsigned long long vhi) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (vb + 16 > vlo && vb < vhi) {
+        v = *reinterpret_cast<const uint4*>(vbase + vb);
+        if (vb < vlo || vb + 16 > vhi) {
+            uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long bb = vb + 4 * d + k;
+                    if (bb >= vlo && bb < vhi) m |= 0xFFu << (8 * k);
+                }
+                wds[d] &= m;
+            }
+            v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+    }
+    return v;  // little-endian as loaded: the byte swap to MSB-first dwords happens when the registers are staged,
+               // so that nothing waits for the load where it is issued
+}
 
 // Wave-scope ordering of LDS traffic between lanes of ONE wave (LDS executes a wave's operations in
 // issue order; this only stops the compiler from reordering across it).

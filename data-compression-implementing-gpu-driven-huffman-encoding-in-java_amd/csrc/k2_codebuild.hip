@@ -107,6 +107,34 @@ __device__ void build_lengths(CodeLds& L, const unsigned long long (&hf)[4]) {
         __syncthreads();
         return;
     }
+    // Balanced case, decided without the queue: 2^k symbols whose largest count is below twice the smallest.  Then the
+    // two lightest leaves together outweigh every leaf, so buildCodeLengths (core/CanonicalHuffman.java:66-70) pairs up all
+    // leaves before it polls an internal node, the 2^(k-1) internal nodes again satisfy max < 2 * min, and by induction the
+    // tree is complete: every symbol gets length k whatever order equal weights are polled in.  This is the reference's
+    // own high-entropy case (256 symbols, all lengths 8) and skips the ~1000 dependent heap operations below.
+    {
+        unsigned long long mn = ~0ull, mx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (hf[i] > 0 && hf[i] < mn) mn = hf[i];
+            if (hf[i] > mx) mx = hf[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = __shfl_xor(mn, o, 64), c = __shfl_xor(mx, o, 64);
+            mn = a < mn ? a : mn;
+            mx = c > mx ? c : mx;
+        }
+        if ((nsym & (nsym - 1)) == 0 && mx < 2ull * mn) {  // wave-uniform
+            const int k = __builtin_ctz((unsigned)nsym);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (hf[i] > 0) L.len[4 * tid + i] = (uint8_t)k;
+            if (tid == 0) L.maxlen = k;
+            __syncthreads();
+            return;
+        }
+    }
     if (tid == 0) {
         int size = 0;
         for (int s = 0; s < 256; s++) {  // core/CanonicalHuffman.java:59-63: leaves in symbol order
@@ -242,7 +270,8 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
     }
     bits = wave_reduce_add_u64(bits);
     if (tid == 0) {
-        d_maxlen[b] = (uint8_t)(too_long ? 0 : maxlen);
+        // bit 7: 256 symbols of 8 bits, i.e. codeword(s) = s and the payload is a copy of the input (K3 copies it)
+        d_maxlen[b] = (uint8_t)(too_long ? 0 : (maxlen | ((maxlen == 8 && L.nsym == 256) ? 0x80 : 0)));
         d_comp_size[b] = too_long ? 0u : (uint32_t)((bits + 7) >> 3);
         d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
     }

@@ -250,8 +250,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     const int lane = tid & 63;
 
     if (d_status[b] != DCZ_OK) return;  // workgroup-uniform
-    const uint32_t maxlen = d_maxlen[b];
+    const uint32_t maxlen_flag = d_maxlen[b];
+    const uint32_t maxlen = maxlen_flag & 0x7Fu;
     const bool wide = maxlen > 26;
+    if (maxlen_flag & 0x80u) return;  // 256 symbols of 8 bits: the payload is the input, k3_copy_identity wrote it
 
     // codebook -> LDS
     uint32_t* lut = lds;
@@ -374,10 +376,62 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
     ring_flush(st, own_end, lane);
 }
 
+// Blocks whose code is 256 symbols of 8 bits (K2 sets bit 7 of d_maxlen): codeword(s) = s (CanonicalHuffman.java:123-129
+// assigns ascending codes in symbol order), so encodeChunk's output (CpuCompressionService.java:303-315) is the input
+// itself -- the reference's high-entropy case (app/logs/datacomp.log:3254).  A flat grid of one workgroup per (block,
+// 16 KiB tile) over all blocks copies them with non-temporal 16 B/lane accesses (see k4_fixed.hip for why flat); a
+// workgroup of any other block leaves after one byte load, and k3_encode leaves at once for the blocks handled here.
+constexpr uint32_t CP_TILE = 16384;
+__global__ __launch_bounds__(256) void k3_copy_identity(const uint8_t* __restrict__ in, size_t n, size_t block_bytes,
+                                                        uint32_t tiles_per_block, uint32_t b0,
+                                                        const uint8_t* __restrict__ d_maxlen,
+                                                        const unsigned long long* __restrict__ d_comp_off,
+                                                        const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
+    const uint32_t bq = blockIdx.x / tiles_per_block;
+    const uint32_t tile = blockIdx.x - bq * tiles_per_block;
+    const uint32_t b = b0 + bq;
+    if ((d_maxlen[b] & 0x80u) == 0u || d_status[b] != DCZ_OK) return;  // workgroup-uniform
+    const uint64_t bstart = (uint64_t)b * block_bytes;
+    const uint64_t bend = (bstart + block_bytes < n) ? bstart + block_bytes : (uint64_t)n;
+    const uint64_t t0 = (uint64_t)tile * CP_TILE;
+    if (bstart + t0 >= bend) return;
+    const uint32_t nout = (bend - bstart - t0 < CP_TILE) ? (uint32_t)(bend - bstart - t0) : CP_TILE;
+    const uint8_t* src = in + bstart + t0;
+    uint8_t* dst = out + d_comp_off[b] + t0;
+    const int tid = (int)threadIdx.x;
+    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0u && nout == CP_TILE) {
+        const u32x4* s4 = reinterpret_cast<const u32x4*>(src) + tid;
+        u32x4* d4 = reinterpret_cast<u32x4*>(dst) + tid;
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(s4 + 256 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], d4 + 256 * k);
+    } else if (((((uintptr_t)src) | ((uintptr_t)dst)) & 3u) == 0u) {
+        const uint32_t nw = nout >> 2;
+        for (uint32_t i = (uint32_t)tid; i < nw; i += 256u)
+            reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+        for (uint32_t i = (nw << 2) + (uint32_t)tid; i < nout; i += 256u) dst[i] = src[i];
+    } else {
+        for (uint32_t i = (uint32_t)tid; i < nout; i += 256u) dst[i] = src[i];
+    }
+}
+
 void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,
                    const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
                    const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s) {
     if (K == 0) return;
+    {
+        const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;
+        const uint64_t tpb = (eff + CP_TILE - 1) / CP_TILE;
+        const uint64_t per = (0x40000000ull / tpb) ? (0x40000000ull / tpb) : 1;  // blocks per launch (grid < 2^31)
+        for (uint64_t b0 = 0; b0 < K; b0 += per) {
+            const uint64_t kb = (K - b0 < per) ? K - b0 : per;
+            hipLaunchKernelGGL(k3_copy_identity, dim3((uint32_t)(kb * tpb)), dim3(256), 0, s, d_in, n, block_bytes,
+                               (uint32_t)tpb, (uint32_t)b0, d_maxlen,
+                               reinterpret_cast<const unsigned long long*>(d_comp_off), d_status, d_out);
+        }
+    }
     const uint32_t gpb = (segs_per_block + K3_WAVES - 1) / K3_WAVES;
     hipLaunchKernelGGL(k3_encode, dim3(K * gpb), dim3(K3_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block, gpb,
                        d_len, d_code, d_maxlen, reinterpret_cast<const unsigned long long*>(d_comp_off),

@@ -109,6 +109,16 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #ifndef DCZ_K4S_NS
 #define DCZ_K4S_NS 1
 #endif
+#ifndef DCZ_K4_TBS
+#define DCZ_K4_TBS DCZ_K4_TB  // first-level table bits of the short-code (multi-symbol) instantiation
+#endif
+// class boundary medium / short codes: a block is of the medium class when orig * A <= csize * B (>= 8 * A / B bits per symbol)
+#ifndef DCZ_K4_CLS2_A
+#define DCZ_K4_CLS2_A 4
+#endif
+#ifndef DCZ_K4_CLS2_B
+#define DCZ_K4_CLS2_B 9
+#endif
 
 template <int W, int NS, int OC, int PV, bool MULTI, int TBITS>
 struct DecLds {
@@ -263,31 +273,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, LdsT& L, ui
     return base + inc - v;
 }
 
-// Load one 16-byte chunk of the payload (virtual byte vb), zero outside [vlo, vhi).
-__device__ __forceinline__ uint4 load_chunk(const uint8_t* vbase, unsigned long long vb, unsigned long long vlo,
-                                            unsigned long long vhi) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (vb + 16 > vlo && vb < vhi) {
-        v = *reinterpret_cast<const uint4*>(vbase + vb);
-        if (vb < vlo || vb + 16 > vhi) {
-            uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const unsigned long long bb = vb + 4 * d + k;
-                    if (bb >= vlo && bb < vhi) m |= 0xFFu << (8 * k);
-                }
-                wds[d] &= m;
-            }
-            v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-        }
-    }
-    return v;  // little-endian as loaded: the byte swap to MSB-first dwords happens when the registers are staged,
-               // so that nothing waits for the load where it is issued
-}
-
 // ---- exact entries for windows that do not self-synchronise ------------------------------------------------------
 // Streams of (nearly) equal-length codewords whose length does not divide the subsequence keep a wrong phase for ever, so
 // the fixed point of phase A advances one subsequence per round.  After DCZ_K4_EXACT_AFTER rounds a window switches to
@@ -409,10 +394,12 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
     constexpr bool XM = MODE == 1;
+    // class byte of the block (k4_classify, then the probe): 0 = table walk, 1 = exact-entry launch, 0x10 | L = fixed-length
+    // code (k4_fixed), 0xFF = footer fields outside the buffers (nobody touches the block)
     if constexpr (MODE == 1) {
-        if (d_slow[b] == 0) return;  // workgroup-uniform: only the blocks the probe flagged
-    } else if constexpr (MODE == 0 && DCZ_K4_EXACT && !MULTI) {
-        if (d_slow[b] != 0) return;  // the exact-entry launch decodes this block
+        if (d_slow[b] != 1) return;  // workgroup-uniform: only the blocks the probe flagged
+    } else {
+        if (d_slow[b] != 0) return;  // another launch owns this block
     }
 
     // ---- block geometry ----
@@ -421,7 +408,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     const uint32_t csize = d_comp_size[b];
     {
         const int cls = ((unsigned long long)csize * 16ull >= (unsigned long long)orig * 13ull) ? 4
-                        : ((unsigned long long)orig * 4ull <= (unsigned long long)csize * 9ull) ? 2 : 1;
+                        : ((unsigned long long)orig * (unsigned long long)DCZ_K4_CLS2_A <= (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B) ? 2 : 1;
         if ((cls & CMASK) == 0) return;  // workgroup-uniform; another launch owns this block
     }
 
@@ -536,7 +523,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     const uint8_t* const vbase = reinterpret_cast<const uint8_t*>(pay - skew);
     const unsigned long long vlo = skew;                              // first valid virtual byte
     const unsigned long long vhi = (unsigned long long)skew + csize;  // one past the last valid virtual byte
-    (void)comp_bytes;
+    (void)comp_bytes;  // checked against coff + csize by k4_classify
 
     // Park symbols only when a 32-byte subsequence is expected to hold at most 3/4 of the register capacity
     // (expected symbols = 32 * orig / csize from the block's own sizes); otherwise too many subsequences
@@ -577,8 +564,8 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     auto prefetch = [&](unsigned long long wchunk0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++)
-            pre[c] = load_chunk(vbase, (wchunk0 + (unsigned long long)(tid * NCH + c)) << 4, vlo, vhi);
-        if (tid == W - 1) pre_m = load_chunk(vbase, (wchunk0 + (unsigned long long)(W * NCH)) << 4, vlo, vhi);
+            pre[c] = load_chunk16(vbase, (wchunk0 + (unsigned long long)(tid * NCH + c)) << 4, vlo, vhi);
+        if (tid == W - 1) pre_m = load_chunk16(vbase, (wchunk0 + (unsigned long long)(W * NCH)) << 4, vlo, vhi);
     };
     if (orig > 0) prefetch(ventry >> 7);
 
@@ -1196,11 +1183,14 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
 
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                   int32_t* d_status, int64_t* d_errpos, uint8_t* d_slow, hipStream_t s) {
+                   int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, hipStream_t s) {
     if (K == 0) return;
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
-    (void)hipMemsetAsync(d_slow, 0, K, s);
+    uint8_t* const d_slow = ws.cls;
+    // class byte of every block (bounds of the footer fields, fixed-length codes), then the analytic decoder for the latter
+    launch_classify(d_len, d_comp_off, d_comp_size, d_orig_size, comp_bytes, out_stride, K, ws, d_status, d_errpos, s);
+    launch_decode_fixed(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, ws, s);
     // Below this many blocks one 1024-thread workgroup per block keeps more waves resident than 256-thread ones.
     static const uint32_t few_below = [] {
         const char* e = getenv("DCZ_K4_FEW_BLOCKS_BELOW");  // tuning knob
@@ -1217,7 +1207,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 #endif
         DCZ_K4_LAUNCH(DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 0);
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 0);
-        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TB, 0);
+        DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 1);
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 1);
@@ -1229,7 +1219,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 #endif
         DCZ_K4_LAUNCH(1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 0);
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 0);
-        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TB, 0);
+        DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 1);
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 1);

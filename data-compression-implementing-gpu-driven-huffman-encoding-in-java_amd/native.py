@@ -22,7 +22,7 @@ SEGMENT_BYTES = 32768
 
 # every symbol include/dcz.h declares (tests check the .so exports each one)
 SYMBOLS = [
-    "dcz_device_count", "dcz_ctx_create", "dcz_ctx_destroy", "dcz_strerror", "dcz_last_error", "dcz_ctx_reserve",
+    "dcz_device_count", "dcz_ctx_create", "dcz_ctx_destroy", "dcz_ctx_stream", "dcz_strerror", "dcz_last_error", "dcz_ctx_reserve",
     "dcz_histogram", "dcz_build_codes", "dcz_codes_from_lengths", "dcz_encode_block", "dcz_decode_block",
     "dcz_compress_blocks", "dcz_decompress_blocks", "dcz_ctx_set_profiling", "dcz_ctx_reset_profiling",
     "dcz_ctx_kernel_time", "dcz_sha256_blocks", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
@@ -60,6 +60,8 @@ def lib():
     L.dcz_ctx_create.restype = i32
     L.dcz_ctx_destroy.argtypes = [vp]
     L.dcz_ctx_destroy.restype = None
+    L.dcz_ctx_stream.argtypes = [vp]
+    L.dcz_ctx_stream.restype = vp
     L.dcz_strerror.argtypes = [i32]
     L.dcz_strerror.restype = C.c_char_p
     L.dcz_last_error.argtypes = [vp]
@@ -119,6 +121,11 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    @property
+    def stream_handle(self):
+        """hipStream_t of the context's own stream (what a NULL stream argument means)."""
+        return lib().dcz_ctx_stream(self.handle)
 
     @property
     def handle(self):

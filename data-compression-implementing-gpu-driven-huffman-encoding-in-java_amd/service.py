@@ -116,6 +116,12 @@ class HipCompressionService:
         self.ctx = nv.Context(device)
         self.batch_bytes = max(int(batch_bytes), self.chunk_size_bytes)
         self.last_stage_metrics = StageMetrics()
+        # The library runs on the stream it is handed; a NULL handle means the context's private non-blocking stream,
+        # which is NOT ordered with torch's streams.  The service wraps that stream for torch and orders it before and
+        # after every call with the caller's current torch stream, so that tensors produced by torch ops (fills,
+        # collectives) and by the kernels see each other in program order without host synchronisation.
+        self._dev = torch.device("cuda", device)
+        self.stream = torch.cuda.ExternalStream(self.ctx.stream_handle, device=self._dev)
 
     # ---- interface methods -------------------------------------------------------------------
     def get_service_name(self):
@@ -129,6 +135,19 @@ class HipCompressionService:
 
     def close(self):
         self.ctx.close()
+
+    def _enter(self, stream, dev):
+        """-> (raw hipStream_t handle to launch on, caller's torch stream or None).  With stream=None the service
+        stream first waits for everything the caller's current stream has queued."""
+        if stream is not None:
+            return stream, None
+        cur = self.torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        return self.stream.cuda_stream, cur
+
+    def _leave(self, cur):
+        if cur is not None:
+            cur.wait_stream(self.stream)  # later torch work on the caller's stream sees the kernels' results
 
     def resume_compression(self, input_path, output_path, last_completed_chunk, progress_callback=None):
         # UnsupportedOperationException in both reference services (CpuCompressionService.java:636-641)
@@ -149,11 +168,12 @@ class HipCompressionService:
                                torch.empty((max(K, 1), 256), dtype=torch.uint8, device=dev)[:K],
                                torch.empty(max(K, 1), dtype=torch.int32, device=dev)[:K],
                                torch.zeros(1, dtype=torch.int64, device=dev), n, bb)
-        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        s, cur = self._enter(stream, dev)
         self.ctx.check(nv.lib().dcz_compress_blocks(
             self.ctx.handle, t_in.data_ptr(), n, bb, out.payload.data_ptr(), int(out.payload.numel()),
             out.comp_size.data_ptr(), out.comp_off.data_ptr(), out.code_lengths.data_ptr(), out.status.data_ptr(),
             out.total.data_ptr(), s))
+        self._leave(cur)
         out.n, out.block_bytes = n, bb
         return out
 
@@ -168,11 +188,12 @@ class HipCompressionService:
             status = torch.zeros(max(K, 1), dtype=torch.int32, device=dev)
         if errpos is None:
             errpos = torch.zeros(max(K, 1), dtype=torch.int64, device=dev)
-        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        s, cur = self._enter(stream, dev)  # after the allocations / fills above, which run on the caller's stream
         self.ctx.check(nv.lib().dcz_decompress_blocks(
             self.ctx.handle, payload.data_ptr(), int(payload.numel()), comp_off.data_ptr(), comp_size.data_ptr(),
             orig_size.data_ptr(), code_lengths.data_ptr(), K, int(out_stride), t_out.data_ptr(), status.data_ptr(),
             errpos.data_ptr(), s))
+        self._leave(cur)
         return t_out, status, errpos
 
     def sha256_device(self, t, block_bytes, stream=None):
@@ -182,10 +203,9 @@ class HipCompressionService:
         bb = int(block_bytes)
         K = (n + bb - 1) // bb
         out = torch.empty((max(K, 1), 32), dtype=torch.uint8, device=t.device)
-        s = stream if stream is not None else torch.cuda.current_stream(t.device).cuda_stream
+        s, cur = self._enter(stream, t.device)
         self.ctx.check(nv.lib().dcz_sha256_blocks(self.ctx.handle, t.data_ptr(), n, bb, out.data_ptr(), s))
-        if stream is None:  # the digests are read by the host next: wait for the context's stream
-            torch.cuda.synchronize(t.device)
+        self._leave(cur)
         return out[:K]
 
     # one lane per chunk: below this many chunks in a batch the host's hashlib is faster

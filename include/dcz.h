@@ -51,6 +51,11 @@ int dcz_ctx_create(int device, dcz_ctx** out);
 /* CompressionService.close (service/gpu/GpuCompressionService.java:1563-1593). */
 void dcz_ctx_destroy(dcz_ctx* ctx);
 
+/* The context's own stream (a hipStream_t, created non-blocking): what every entry point runs on when its `stream`
+ * argument is NULL.  Hosts that mix library calls with their own HIP work order the two with events on this handle
+ * (the Python mirror wraps it in torch.cuda.ExternalStream). */
+void* dcz_ctx_stream(dcz_ctx* ctx);
+
 const char* dcz_strerror(int status);
 const char* dcz_last_error(const dcz_ctx* ctx);
 

@@ -887,3 +887,117 @@ def test_exact_entry_decoder_reports_damage_like_the_reference(pkg, svc, orc):
         else:
             assert (out[k * stride:k * stride + nsym] == wdata).all(), "block %d decodes differently" % k
     assert nerr > 20
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fixed-length complete codes (2^L symbols, every code L bits): decoded analytically by k4_fixed over many workgroups
+# per block; K3 copies blocks of 256 8-bit symbols.  Reference semantics: TableBasedHuffmanDecoder.java:78-88, 103-134.
+def _fixed_data(rng, L, n):
+    syms = np.sort(rng.choice(256, size=1 << L, replace=False)).astype(np.uint8)
+    # a balanced multiset (every symbol floor/ceil(n / 2^L) times), shuffled: max count < 2 * min count => all lengths L
+    reps = -(-n // (1 << L))
+    data = np.tile(syms, reps)[:n].copy()
+    rng.shuffle(data)
+    return data
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("n,bb", [(5 * 65536 + 4321, 65536), (3 * 100000, 100000), (1 << 21, 1 << 21), (40000, 70001)])
+def test_parity_fixed_length_codes(svc, orc, L, n, bb):
+    rng = np.random.default_rng(1000 * L + n % 977)
+    data = _fixed_data(rng, L, n)
+    blk = assert_parity(svc, orc, data, bb)
+    lens = blk.code_lengths.cpu().numpy()
+    fixed = [((l == 0) | (l == L)).all() and (l == L).sum() == (1 << L) for l in lens]
+    assert any(fixed)  # (a short last block may have a skewed histogram and an ordinary Huffman code)
+
+
+def test_fixed_length_blocks_with_truncated_and_oversized_requests(pkg, svc, orc):
+    """Zero bits past the payload (TableBasedHuffmanDecoder.java:204-208) and symbol counts beyond the payload, for
+    the analytic decoder, against the oracle's decoder; payload offsets of every alignment."""
+    rng = np.random.default_rng(77)
+    for L in (1, 3, 4, 7, 8):
+        data = _fixed_data(rng, L, 50000 + L)
+        pay, lens = orc.encode_block(data)
+        assert set(np.unique(lens)) <= {0, L}
+        for cut, want in [(pay.size, data.size), (pay.size, data.size + 777), (pay.size // 2, data.size), (3, 100), (0, 50)]:
+            comp = pay[:cut] if cut else np.zeros(0, np.uint8)
+            assert (svc.decode_chunk(comp, lens, want) == orc.decode_block(comp, lens, want)).all(), (L, cut, want)
+    # many blocks at once, payload offsets at every byte alignment, mixed with table-walk blocks
+    torch = _torch()
+    K = 70
+    pays, lens_all, origs, want = [], [], [], []
+    for k in range(K):
+        L = 1 + k % 8
+        n = 30000 + 17 * k
+        d = _fixed_data(rng, L, n) if k % 5 else orc.gen_text(k, 0, n)
+        p, l = orc.encode_block(d)
+        pays.append(np.concatenate([p, np.zeros(k % 16, np.uint8)]))  # slack bytes shift the next payload's alignment
+        lens_all.append(l.astype(np.uint8))
+        origs.append(n)
+        want.append(d)
+    sizes = np.array([p.size - (k % 16) for k, p in enumerate(pays)], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum([p.size for p in pays][:-1])]).astype(np.int64)
+    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
+    stride = (max(origs) + 15) & ~15
+    out, st, _ = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                       torch.tensor(origs, dtype=torch.int32, device="cuda"),
+                                       torch.from_numpy(np.stack(lens_all)).cuda(), stride)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy()[:K] == 0).all()
+    o = out.cpu().numpy()
+    for k in range(K):
+        assert (o[k * stride:k * stride + origs[k]] == want[k]).all(), "block %d" % k
+
+
+def test_footer_fields_outside_the_buffers_are_rejected(pkg, svc, orc):
+    """dcz_decompress_blocks takes untrusted footer fields: offset/size beyond the payload buffer or an original size
+    beyond the output stride give DCZ_E_INVALID for that block and nothing is read or written for it."""
+    torch = _torch()
+    data = orc.gen_text(3, 0, 4 * 20000)
+    blk, pay, sizes, offs, lens, status = hip_compress(svc, data, 20000)
+    K = 4
+    total = int(pay.size)
+    payload = blk.payload[:total + 16].clone()
+    orig = np.full(K, 20000, np.int32)
+    stride = 20000 + 16
+    cases = [("offset", 1, offs.astype(np.int64) + np.array([0, total, 0, 0]), sizes, orig),
+             ("size", 2, offs.astype(np.int64), sizes.astype(np.int64) + np.array([0, 0, total, 0]), orig),
+             ("orig", 3, offs.astype(np.int64), sizes, orig + np.array([0, 0, 0, 64], np.int32))]
+    for name, bad, o_, s_, g_ in cases:
+        sentinel = torch.full((K * stride,), 0xA5, dtype=torch.uint8, device="cuda")
+        out, st, ep = svc.decompress_device(payload[:total], torch.from_numpy(np.asarray(o_, np.int64)).cuda(),
+                                            torch.from_numpy(np.asarray(s_, np.int64).astype(np.int32)).cuda(),
+                                            torch.from_numpy(np.asarray(g_, np.int32)).cuda(), blk.code_lengths, stride,
+                                            t_out=sentinel)
+        torch.cuda.synchronize()
+        st = st.cpu().numpy()[:K]
+        assert st[bad] == pkg.native.DCZ_E_INVALID, name
+        assert (np.delete(st, bad) == 0).all(), name
+        o = out.cpu().numpy()
+        assert (o[bad * stride:(bad + 1) * stride] == 0xA5).all(), name + ": the rejected block was written"
+        for k in range(K):
+            if k != bad:
+                assert (o[k * stride:k * stride + 20000] == data[k * 20000:(k + 1) * 20000]).all()
+
+
+def test_torch_ops_and_kernels_are_ordered_without_host_sync(pkg, svc, orc):
+    """Tensors written by the kernels (on the service's stream) and torch ops queued right after on the caller's stream
+    -- what sharding.gather_chunk_sizes does between compress and decompress -- must see each other in program order."""
+    torch = _torch()
+    from dcz_amd import sharding
+    n, bb = 64 << 20, 1 << 20
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().dczu_fill_text(svc.ctx.handle, t.data_ptr(), n, 5, 0, svc.stream.cuda_stream) == 0
+    torch.cuda.synchronize()
+    blk = svc.compress_device(t, bb)
+    ref_sizes = blk.comp_size.clone()
+    torch.cuda.synchronize()
+    want = ref_sizes.cpu().numpy().astype(np.int64)
+    for _ in range(5):
+        blk.comp_size.zero_()  # queued on the caller's stream: must land BEFORE the kernels rewrite the sizes
+        blk = svc.compress_device(t, bb, out=blk)
+        all_sizes, offsets, base = sharding.gather_chunk_sizes(blk.comp_size, blk.num_chunks)  # no host sync in between
+        got = all_sizes.cpu().numpy()
+        assert (got == want).all()
+        assert (offsets.cpu().numpy() == np.concatenate([[0], np.cumsum(want)[:-1]])).all()
