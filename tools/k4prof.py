@@ -18,9 +18,22 @@ for name, fill, seed, n, bb in [("rand2g", lib.dczu_fill_java_random, 42, 2 << 3
     orig = torch.full((K,), bb, dtype=torch.int32, device="cuda")
     buf = (ctypes.c_ulonglong * 12)()
     prof(buf, 1)
+    if hasattr(lib, "dcz_debug_rw_prof"):
+        lib.dcz_debug_rw_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.dcz_debug_rw_prof((ctypes.c_ulonglong * 12)(), 1)
     out, st, ep = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb)
     torch.cuda.synchronize()
     prof(buf, 1)
     v = np.array(list(buf)[:8], dtype=np.float64)
     print("   windows %d, self-sync rounds per window %.2f" % (buf[8], buf[9] / max(1, buf[8])))
-    print(name, "ok", bool(torch.equal(out[:n], t)), " ".join("%s %.1f%%" % (nm, 100 * x / v.sum()) for nm, x in zip(names, v)))
+    print(name, "ok", bool(torch.equal(out[:n], t)), " ".join("%s %.1f%%" % (nm, 100 * x / max(1, v.sum())) for nm, x in zip(names, v)))
+    if hasattr(lib, "dcz_debug_rw_prof"):  # k4_regwin.hip (medium class)
+        rp = lib.dcz_debug_rw_prof
+        rp.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        rb = (ctypes.c_ulonglong * 12)()
+        rp(rb, 1)
+        rv = np.array(list(rb)[:8], dtype=np.float64)
+        rn = ["tables", "staging", "A walk", "A barrier", "scan+err+prefetch", "B emit", "B barrier", "flush"]
+        if rb[8]:
+            print("   regwin: windows %d, rounds/window %.2f, flushes/window %.2f, cycles/window (wave 0) %.0f | %s" % (
+                rb[8], rb[9] / rb[8], rb[10] / rb[8], rv.sum() / rb[8], " ".join("%s %.1f%%" % (a, 100 * x / rv.sum()) for a, x in zip(rn, rv))))
