@@ -581,6 +581,22 @@ int dcz_ctx_kernel_time(dcz_ctx* c, int kernel, double* total_ms, uint64_t* laun
     return r;
 }
 
+/* debug / tools only (not declared in include/dcz.h): raw bytes of the decoder workspace after the stream has drained */
+int dcz_debug_read_decode_ws(dcz_ctx* c, void* dst, size_t offset, size_t n) {
+    if (!c || !c->dws || offset + n > decode_ws_bytes(c->cap_dws_K)) return DCZ_E_INVALID;
+    DeviceGuard dg(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, c->dws + offset, n, hipMemcpyDeviceToHost));
+    return DCZ_OK;
+}
+size_t dcz_debug_decode_ws_layout(dcz_ctx* c, size_t* split_offset, size_t* split_entries) {
+    if (!c) return 0;
+    const size_t kb = (c->cap_dws_K + 255) & ~(size_t)255;
+    if (split_offset) *split_offset = kb + 256;
+    if (split_entries) *split_entries = SPLIT_ENTRIES;
+    return decode_ws_bytes(c->cap_dws_K);
+}
+
 int dcz_sha256_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_bytes, void* d_digests, void* stream) {
     if (!c || (!d_in && n) || block_bytes == 0 || (!d_digests && n)) return DCZ_E_INVALID;
     const size_t K = (n + block_bytes - 1) / block_bytes;

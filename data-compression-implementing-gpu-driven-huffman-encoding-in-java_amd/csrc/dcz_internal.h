@@ -35,14 +35,32 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
                    const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
                    const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s);
 
-// K4: decode.  Workspace of one decode call (device memory, see decode_ws_bytes).
-struct DecodeWs {
-    uint8_t* cls;  // K x u8: class byte of every block (k4_classify, then the probe launch)
+// K4: decode.  Region table of the split decoder (k4_split.hip): a block cut into regions of region_bytes of payload,
+// one workgroup per region; the arrays are [block][rmax].
+struct SplitDesc {
+    uint32_t* entry;   // bits from the region's first payload bit (virtual) to its first codeword
+    uint32_t* count;   // symbols the region produces
+    uint32_t* exit;    // bits from the region's end to the first codeword past it, 0xFFFFFFFF = not usable
+    uint32_t* off;     // output offset of the region inside its chunk
+    uint32_t* nreg;    // [block] regions in use, 0 = the block is not split
+    uint32_t rmax;
+    uint32_t pad;
+    unsigned long long region_bytes;
 };
-inline size_t decode_ws_bytes(size_t K) { return K + 64; }
+constexpr size_t SPLIT_MAX_BLOCKS = 128;      // blocks per call below which a call may be split
+constexpr size_t SPLIT_REGIONS = 2048;        // regions aimed at per call
+constexpr size_t SPLIT_ENTRIES = SPLIT_MAX_BLOCKS * (SPLIT_REGIONS + 2);
+// Workspace of one decode call (device memory, see decode_ws_bytes).
+struct DecodeWs {
+    uint8_t* cls;        // K x u8: class byte of every block (k4_classify, then the probe launch / k4_split_scan)
+    SplitDesc* sdesc;    // device copy of the region table descriptor of this call
+    uint32_t* split;     // 4 x SPLIT_ENTRIES + SPLIT_MAX_BLOCKS u32
+};
+inline size_t decode_ws_bytes(size_t K) { return ((K + 255) & ~(size_t)255) + 256 + (4 * SPLIT_ENTRIES + SPLIT_MAX_BLOCKS) * 4; }
 inline DecodeWs decode_ws_at(void* base, size_t K) {
-    (void)K;
-    return DecodeWs{static_cast<uint8_t*>(base)};
+    uint8_t* p = static_cast<uint8_t*>(base);
+    const size_t kb = (K + 255) & ~(size_t)255;
+    return DecodeWs{p, reinterpret_cast<SplitDesc*>(p + kb), reinterpret_cast<uint32_t*>(p + kb + 256)};
 }
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
@@ -55,6 +73,10 @@ void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
                          const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
                          const DecodeWs& ws, hipStream_t s);
 
+// k4_split.hip: regions of few large blocks: counting pass + proof/scan (fills the tables of sd, sets class byte 2)
+void launch_split_count(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                        const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, uint8_t* d_cls, int32_t* d_status,
+                        int64_t* d_errpos, const SplitDesc& sd, SplitDesc* d_sd, hipStream_t s);
 // k4_regwin.hip: table walk for the medium class (register window, multi-symbol tables)
 void launch_decode_regwin(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                           const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,

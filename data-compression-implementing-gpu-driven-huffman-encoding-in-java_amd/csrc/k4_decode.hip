@@ -377,38 +377,52 @@ __device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds
 // MODE 2: the probe, launched first: table build and phase A of the block's FIRST window only; a block whose window is not
 //         synchronised after DCZ_K4_EXACT_AFTER rounds is flagged in d_slow.
 // MODE 1: the exact-entry decoder, launched last: decodes the flagged blocks with k4_exact_entries in every window.
+// MODE 3: the regular decoder run once per REGION of a block that k4_split.hip has cut up (sdp: the region table).
 // Keeping the probe's give-up test and the exact-entry call out of the regular kernels keeps their register allocation
 // what it was (with either inside, the uniform case lost 9-14 %).
 template <int W, int NS, int OC, int PV, bool MULTI, int CMASK, int TBITS, int MODE>
-__global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAVES : 4) : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
+__global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAVES : 4) : 1) void k4_decode(const uint8_t* __restrict__ comp, size_t comp_bytes,
                                                const unsigned long long* __restrict__ d_comp_off,
                                                const uint32_t* __restrict__ d_comp_size,
                                                const uint32_t* __restrict__ d_orig_size,
                                                const uint8_t* __restrict__ d_len, size_t out_stride,
                                                uint8_t* __restrict__ out, int32_t* __restrict__ d_status,
-                                               long long* __restrict__ d_errpos, uint8_t* __restrict__ d_slow) {
+                                               long long* __restrict__ d_errpos, uint8_t* __restrict__ d_slow,
+                                               const SplitDesc* __restrict__ sdp) {
     using LdsT = DecLds<W, NS, OC, PV, MULTI, TBITS>;
     __shared__ LdsT L;
     constexpr int TB = TBITS;
     constexpr int NCH = 2 * NS;  // 16-byte chunks per thread
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
     constexpr bool XM = MODE == 1;
-    // class byte of the block (k4_classify, then the probe): 0 = table walk, 1 = exact-entry launch, 0x10 | L = fixed-length
-    // code (k4_fixed), 0xFF = footer fields outside the buffers (nobody touches the block)
-    if constexpr (MODE == 1) {
+    // class byte of the block (k4_classify, then the probe / k4_split_scan): 0 = table walk, one workgroup per block,
+    // 1 = exact-entry launch, 2 = table walk, one workgroup per REGION (k4_split.hip), 0x10 | L = fixed-length code
+    // (k4_fixed), 0xFF = footer fields outside the buffers (nobody touches the block)
+    constexpr bool split = MODE == 3;  // MODE 3 = MODE 0 with one workgroup per (block, region): own instantiations, so
+                                       // that the per-block kernels keep their register allocation
+    uint32_t reg = 0;
+    if constexpr (split) {
+        const uint32_t rmax = sdp->rmax;
+        b = blockIdx.x / rmax;
+        reg = blockIdx.x - b * rmax;
+        if (d_slow[b] != 2 || reg >= sdp->nreg[b]) return;  // workgroup-uniform
+    } else if constexpr (MODE == 1) {
         if (d_slow[b] != 1) return;  // workgroup-uniform: only the blocks the probe flagged
     } else {
         if (d_slow[b] != 0) return;  // another launch owns this block
     }
 
     // ---- block geometry ----
-    const uint32_t orig = d_orig_size[b];
+    const uint32_t orig_blk = d_orig_size[b];
     const unsigned long long coff = d_comp_off[b];
     const uint32_t csize = d_comp_size[b];
+    // symbols this workgroup produces: the whole chunk, or what k4_split_scan gave its region
+    const uint32_t orig = split ? sdp->count[(uint64_t)b * sdp->rmax + reg] : orig_blk;
+    if (split && orig == 0u) return;
     {
-        const int cls = ((unsigned long long)csize * 16ull >= (unsigned long long)orig * 13ull) ? 4
-                        : ((unsigned long long)orig * (unsigned long long)DCZ_K4_CLS2_A <= (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B) ? 2 : 1;
+        const int cls = ((unsigned long long)csize * 16ull >= (unsigned long long)orig_blk * 13ull) ? 4
+                        : ((unsigned long long)orig_blk * (unsigned long long)DCZ_K4_CLS2_A <= (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B) ? 2 : 1;
         if ((cls & CMASK) == 0) return;  // workgroup-uniform; another launch owns this block
     }
 
@@ -514,9 +528,14 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     const uint32_t zlen = L.maxlen ? L.len8[zsym] : 1u;          // entries of mout
     // block-uniform: a 1-bit symbol and < 1.3 bits per symbol on average (from the block's own sizes)
     const bool sparse = MULTI && DCZ_K4_SPARSE && zlen == 1u && L.maxlen > 1u &&
-                        (unsigned long long)csize * 80ull < (unsigned long long)orig * 13ull;
-    uint8_t* const oblk = out + (uint64_t)b * out_stride;
-    const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
+                        (unsigned long long)csize * 80ull < (unsigned long long)orig_blk * 13ull;
+    // output of this workgroup: the chunk's slot, or the region's offset inside it.  A region starts at any byte: the
+    // tile is then laid over the 16-byte unit that holds its first byte, whose first hskip bytes belong to the
+    // region before and are never stored from here.
+    uint8_t* const oblk = out + (uint64_t)b * out_stride + (split ? sdp->off[(uint64_t)b * sdp->rmax + reg] : 0u);
+    uint32_t hskip = (split && !sparse) ? (uint32_t)(((uintptr_t)oblk) & 15u) : 0u;
+    uint8_t* const obase = oblk - hskip;  // address of tile byte 0 of the first flush
+    const bool out_aligned = (((uintptr_t)obase) & 15u) == 0u;
     // virtual byte 0 = 16-byte aligned address at or below the payload start
     const uintptr_t pay = (uintptr_t)comp + (uintptr_t)coff;
     const uint32_t skew = (uint32_t)(pay & 15u);
@@ -529,12 +548,13 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
     // (expected symbols = 32 * orig / csize from the block's own sizes); otherwise too many subsequences
     // overflow and are decoded twice anyway.
     const bool park = LdsT::PRIV > 0 &&
-                      (unsigned long long)orig * 128ull <= (unsigned long long)csize * 3ull * (unsigned long long)LdsT::PRIV;
+                      (unsigned long long)orig_blk * 128ull <= (unsigned long long)csize * 3ull * (unsigned long long)LdsT::PRIV;
     bool slow_block = XM;                     // exact-entry instantiation: every window starts from exact entries
-    unsigned long long ventry = 8ull * skew;  // virtual bit of the next codeword boundary
+    // virtual bit of the next codeword boundary: the payload start, or the region's proven entry
+    unsigned long long ventry = split ? 8ull * reg * sdp->region_bytes + sdp->entry[(uint64_t)b * sdp->rmax + reg] : 8ull * skew;
     uint32_t produced = 0;                    // symbols decoded so far
-    uint32_t gpos = 0;                        // block-relative output offset of tile byte 0 (multiple of 16)
-    uint32_t ocarry = 0;                      // bytes at the front of the tile not yet stored (0..15)
+    uint32_t gpos = 0;                        // offset of tile byte 0 from obase (multiple of 16)
+    uint32_t ocarry = hskip;                  // bytes at the front of the tile not to be stored from it now (0..15)
     int status = DCZ_OK;
     long long errpos = 0;
 
@@ -1126,15 +1146,15 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             const uint32_t total = ocarry + cc;
             const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
             const uint32_t full = last ? total : (total & ~15u);
-            uint8_t* const dst = oblk + gpos;
+            uint8_t* const dst = obase + gpos;
             const uint32_t nunits = (full + 15u) >> 4;
             for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
                 const uint32_t lo = u << 4;
                 uint32_t* src = &L.outbuf[(lo >> 2) + (lo >> 6)];  // a unit never straddles a pad
-                if (out_aligned && lo + 16u <= full) {
+                if (out_aligned && lo + 16u <= full && lo >= hskip) {
                     *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
                 } else {
-                    for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[opad(i)];
+                    for (uint32_t i = lo > hskip ? lo : hskip; i < lo + 16u && i < full; i++) dst[i] = ob[opad(i)];
                 }
                 if constexpr (LdsT::ZT) src[0] = src[1] = src[2] = src[3] = 0;
             }
@@ -1151,6 +1171,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
             if ((uint32_t)tid < tail) ob[opad((uint32_t)tid)] = tv;
             gpos += full;
             ocarry = tail;
+            if (full > 0u) hskip = 0;  // (the unit shared with the region before has been written)
             cbase = cend;
         }
         produced += lim;
@@ -1158,7 +1179,7 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         if (exhausted && produced < orig) {
             // The payload is used up but the chunk wants more symbols: the reference keeps reading zero bits
             // (TableBasedHuffmanDecoder.java:204-208), i.e. the all-zero codeword = first canonical symbol, forever.
-            if ((uint32_t)tid < ocarry) oblk[gpos + tid] = ob[opad((uint32_t)tid)];  // unflushed tail (gpos + ocarry == produced)
+            if ((uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[opad((uint32_t)tid)];  // unflushed tail
             if (L.maxlen == 0) {  // empty table: no codeword at all
                 status = DCZ_E_BADSTREAM;
                 errpos = (long long)produced;
@@ -1172,9 +1193,11 @@ __global__ __launch_bounds__(W, (W <= 256 && !MULTI) ? (PV <= 48 ? DCZ_K4_MINWAV
         PROF_T(7);
     }
 
-    if (tid == 0) {
+    if (tid == 0 && (!split || status != DCZ_OK)) {  // (a split block got its status from k4_split_scan)
         d_status[b] = status;
-        if (d_errpos) d_errpos[b] = errpos;
+        if (d_errpos) d_errpos[b] = errpos + (split ? (long long)sdp->off[(uint64_t)b * sdp->rmax + reg] : 0ll);
+    }
+    if (tid == 0) {
 #if DCZ_K4_PROF
         for (int i = 0; i < 12; i++) atomicAdd(&k4_prof[i], pacc[i]);
 #endif
@@ -1196,9 +1219,41 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
         const char* e = getenv("DCZ_K4_FEW_BLOCKS_BELOW");  // tuning knob
         return e ? (uint32_t)atoi(e) : 1024u;
     }();
-#define DCZ_K4_LAUNCH(WW, NSS, OCC, PVV, MM, CC, TT, XX)                                                                \
-    hipLaunchKernelGGL((k4_decode<WW, NSS, OCC, PVV, MM, CC, TT, XX>), dim3(K), dim3(WW), 0, s, d_comp, comp_bytes, off, \
-                       d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, d_slow)
+#define DCZ_K4_LAUNCH_G(GRID, SDP, WW, NSS, OCC, PVV, MM, CC, TT, XX)                                                     \
+    hipLaunchKernelGGL((k4_decode<WW, NSS, OCC, PVV, MM, CC, TT, XX>), dim3(GRID), dim3(WW), 0, s, d_comp, comp_bytes, off, \
+                       d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, d_slow, SDP)
+#define DCZ_K4_LAUNCH(WW, NSS, OCC, PVV, MM, CC, TT, XX) \
+    DCZ_K4_LAUNCH_G(K, (const SplitDesc*)nullptr, WW, NSS, OCC, PVV, MM, CC, TT, XX)
+    // Few large blocks (the reference's 16-32 MiB chunks, a single dcz_decode_block call): cut every block into regions,
+    // prove the region entries (k4_split.hip) and run the table-walk kernels once per region.  Blocks that cannot be
+    // proven keep class 0 and are decoded by the per-block launches below.
+    static const uint32_t split_below = [] {
+        const char* e = getenv("DCZ_K4_SPLIT_BELOW");  // tuning knob; 0 = never split
+        return e ? (uint32_t)atoi(e) : (uint32_t)SPLIT_MAX_BLOCKS;
+    }();
+    if (K < split_below && K <= SPLIT_MAX_BLOCKS && comp_bytes / K >= 4u * 65536u) {
+        SplitDesc sd;
+        // regions per block the grid provides for: the smallest region size (64 KiB) applied to the whole payload
+        // buffer, capped by the table space; the region size itself is chosen on the device (k4_split_setup)
+        unsigned long long rm = comp_bytes / 65536ull + 2;
+        if (rm > SPLIT_ENTRIES / K) rm = SPLIT_ENTRIES / K;
+        sd.rmax = (uint32_t)rm;
+        sd.region_bytes = 65536;
+        {
+            sd.entry = ws.split;
+            sd.count = ws.split + SPLIT_ENTRIES;
+            sd.exit = ws.split + 2 * SPLIT_ENTRIES;
+            sd.off = ws.split + 3 * SPLIT_ENTRIES;
+            sd.nreg = ws.split + 4 * SPLIT_ENTRIES;
+            sd.pad = 0;
+            launch_split_count(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, d_slow, d_status, d_errpos, sd,
+                               ws.sdesc, s);
+            const uint32_t grid = K * sd.rmax;
+            DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 3);
+            DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 3);
+            DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 3);
+        }
+    }
     // DCZ_K4_MEDIUM_REGWIN=1 decodes the medium class (3.6 .. 6.5 bits per symbol) with k4_regwin.hip (register-window
     // multi-symbol walk) instead of the parked table walk.  Measured on 8 GiB of text: 16.3 ms against 14.4 ms (it issues
     // fewer LDS operations but more vector instructions, and both kernels are issue-bound), so it is off by default; its
@@ -1247,6 +1302,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 #endif
     }
 #undef DCZ_K4_LAUNCH
+#undef DCZ_K4_LAUNCH_G
 }
 
 }  // namespace dcz

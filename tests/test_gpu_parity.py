@@ -1001,3 +1001,95 @@ def test_torch_ops_and_kernels_are_ordered_without_host_sync(pkg, svc, orc):
         got = all_sizes.cpu().numpy()
         assert (got == want).all()
         assert (offsets.cpu().numpy() == np.concatenate([[0], np.cumsum(want)[:-1]])).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Few large blocks: one block decoded by many workgroups (k4_split.hip: counting pass over regions, proven entries, the
+# table-walk kernels once per region).  The reference's own chunk sizes: 32 MiB (cli/DataCompCLI.java:35) and 16 MiB
+# (application.conf:10); its decodeChunkParallel (CpuCompressionService.java:511-556) is what a single call replaces.
+def _gen_device(pkg, svc, kind, n, seed=None):
+    torch = _torch()
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    lib, h = pkg.lib(), svc.ctx.handle
+    if kind == "text":
+        assert lib.dczu_fill_text(h, t.data_ptr(), n, seed or 0xD0C2, 0, None) == 0
+    elif kind == "lowentropy":
+        assert lib.dczu_fill_lowentropy(h, t.data_ptr(), n, seed or 0xD0C5, 0, None) == 0
+    else:
+        assert lib.dczu_fill_java_random(h, t.data_ptr(), n, seed or 42, 0, None) == 0
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.mark.parametrize("kind", ["text", "lowentropy", "random", "near_uniform"])
+@pytest.mark.parametrize("shape", ["1x32MiB", "3x16MiB", "1x2MiB+", "5x3MiB_ragged"])
+def test_split_decode_of_few_large_blocks(pkg, svc, orc, kind, shape):
+    torch = _torch()
+    n, bb = {"1x32MiB": (32 << 20, 32 << 20), "3x16MiB": (48 << 20, 16 << 20), "1x2MiB+": ((2 << 20) + 12345, 4 << 20),
+             "5x3MiB_ragged": (4 * (3 << 20) + 777777, 3 << 20)}[shape]
+    if kind == "near_uniform":  # 7/8/9-bit codes: the long-code class, not fixed-length
+        rng = np.random.default_rng(3)
+        p = 1.0 + 0.3 * np.sin(np.arange(256))
+        base = rng.choice(256, size=1 << 22, p=p / p.sum()).astype(np.uint8)
+        t = torch.from_numpy(np.resize(base, n)).cuda()
+    else:
+        t = _gen_device(pkg, svc, kind, n)
+    blk = _roundtrip_device(svc, t, bb)
+    # first and last block against the oracle (payload bytes and code lengths), the rest through the round trip
+    data = t.cpu().numpy()
+    K = blk.num_chunks
+    for k in {0, K - 1}:
+        seg = data[k * bb:min(n, (k + 1) * bb)]
+        if seg.size <= (4 << 20):
+            pay, lens = orc.encode_block(seg)
+            o, c = int(blk.comp_off[k]), int(blk.comp_size[k])
+            assert c == pay.size and (blk.payload[o:o + c].cpu().numpy() == pay).all()
+            assert (blk.code_lengths[k].cpu().numpy().astype(np.int32) == lens).all()
+
+
+def test_split_decode_falls_back_on_damaged_and_foreign_streams(pkg, svc, orc):
+    """Blocks that the split decoder cannot prove (damage, truncation, requests beyond the payload) must give exactly what
+    the one-workgroup-per-block path gives: the oracle decoder's bytes, status and error position."""
+    torch = _torch()
+    rng = np.random.default_rng(23)
+    lens = np.zeros(256, np.int32)
+    syms = rng.choice(256, size=48, replace=False)
+    lens[syms] = rng.integers(4, 12, size=48)  # prefix-free but incomplete: damage hits patterns without a codeword
+    codes, _ = orc.canonical_codes(lens)
+    nsym = 1500000
+    cases = []
+    for k in range(6):
+        data = rng.choice(syms, size=nsym + 1000 * k).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        pay = pay.copy()
+        want_n = data.size
+        if k == 1:
+            pay[pay.size // 2] ^= 0x10  # one flipped bit in the middle
+        if k == 2:
+            pay = pay[: pay.size * 2 // 3]  # truncated: zero bits past the end
+        if k == 3:
+            want_n += 5000  # more symbols than the payload holds
+        if k == 4:
+            pay[100] ^= 0x01  # damage inside the first region
+        try:
+            want = (0, 0, orc.decode_block(pay, lens, want_n))
+        except orc.DecodeError as e:
+            want = (pkg.native.DCZ_E_BADSTREAM, e.position, None)
+        cases.append((pay, want_n, want))
+    sizes = np.array([c[0].size for c in cases], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
+    origs = np.array([c[1] for c in cases], dtype=np.int32)
+    payload = torch.from_numpy(np.concatenate([c[0] for c in cases] + [np.zeros(16, np.uint8)])).cuda()
+    stride = (int(origs.max()) + 15) & ~15
+    K = len(cases)
+    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                        torch.from_numpy(origs).cuda(),
+                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
+    torch.cuda.synchronize()
+    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
+    for k, (pay, want_n, (wst, wpos, wdata)) in enumerate(cases):
+        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
+        if wst:
+            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
+        else:
+            assert (out[k * stride:k * stride + want_n] == wdata).all(), "block %d decodes differently" % k

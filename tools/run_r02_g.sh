@@ -1,0 +1,3 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/g_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/g_tests.log
