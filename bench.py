@@ -34,6 +34,12 @@ WORKLOADS = {
              "1GiB/GPU order-0 English-like text (8GiB over 8 GPUs), 4MiB chunks [BASELINE config 4]"),
     "lowentropy": ("lowentropy", 0xD0C5, 8 << 30, 4 << 20,
                    "8GiB/GPU zeros + 1% noise (64GiB over 8 GPUs), 4MiB chunks [BASELINE config 5]"),
+    # the reference's own chunk sizes (cli/DataCompCLI.java:35: 32 MB; application.conf:10: 16 MB): few large chunks,
+    # decoded by many workgroups per chunk (k4_split.hip)
+    "text_32m": ("text", 0xD0C2, 1 << 30, 32 << 20,
+                 "1GiB/GPU order-0 English-like text, 32MiB chunks (the reference CLI's default chunk size)"),
+    "text8g": ("text", 0xD0C2, 8 << 30, 4 << 20,
+               "8GiB/GPU order-0 English-like text, 4MiB chunks [BASELINE config 4 at one GPU's worth of 8 GiB]"),
 }
 
 
@@ -161,16 +167,24 @@ def main():
     dominant = max(alg_bytes, key=lambda nm: kern[nm]["ms_total"])
 
     if rank == 0:
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes
-        if os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    traffic = json.load(f).get(args.workload, {}).get(dominant, {}).get("total")
-                    if traffic is not None:  # the PMC figure is per step; report it per launch like `achieved`
-                        traffic = traffic * args.steps // max(1, kern[dominant]["launches"])
-            except Exception:
-                traffic = None
+        # roofline.traffic: HBM bytes of the dominant kernel family from an OFFLINE rocprofv3 --pmc pass (tools/traffic.sh ->
+        # profiles/pmc_traffic.json); only quoted when that pass ran this very workload shape, otherwise null + the reason
+        traffic, traffic_source = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            with open(pmc_path) as f:
+                ent = json.load(f).get(args.workload, {})
+            if (ent.get("bytes_per_gpu"), ent.get("chunk_bytes")) != (per_gpu, chunk):
+                traffic_source = "null: profiles/pmc_traffic.json has no pass for %s at %d bytes, %d-byte chunks" % (
+                    args.workload, per_gpu, chunk)
+            elif ent.get(dominant, {}).get("total") is None:
+                traffic_source = "null: no counters for %s in profiles/pmc_traffic.json" % dominant
+            else:  # the PMC figure is per step; report it per launch like `achieved`
+                traffic = ent[dominant]["total"] * args.steps // max(1, kern[dominant]["launches"])
+                traffic_source = "profiles/pmc_traffic.json (offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, %s)" % (
+                    ent.get("build", "build not recorded"))
+        except Exception as e:
+            traffic_source = "null: %s" % e
         value = world * per_gpu * args.steps / elapsed / 1e9
         # encode and decode separately (rank 0's own times).  t_dec = the K4 launches of a step,
         # t_enc = the rest of the step (K1/K2/K3 overlap on two streams, so their kernel times do not add up).
@@ -194,6 +208,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(kern[dominant]["gbps"], 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(kern[dominant]["gbps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "alg_bytes_per_launch": kern[dominant]["alg_bytes_per_launch"],
                          "avg_launch_ms": round(kern[dominant]["avg_ms"], 4)},
             "roundtrip_roofline": {"alg_bytes_per_step": 3 * per_gpu + 2 * comp_bytes,

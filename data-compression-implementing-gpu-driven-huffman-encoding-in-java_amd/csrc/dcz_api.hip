@@ -34,6 +34,10 @@ struct dcz_ctx {
     uint8_t* st_out = nullptr;
     size_t st_out_cap = 0;
     uint8_t* st_meta = nullptr;  // 8 KiB of small per-block device fields
+    uint8_t* st_batch = nullptr;  // per-chunk device columns of the host-pointer batch API (grow-only)
+    size_t st_batch_K = 0;
+    void* pinned[2] = {nullptr, nullptr};  // pinned host staging handed out by dcz_ctx_pinned (grow-only)
+    size_t pinned_cap[2] = {0, 0};
     // profiling
     bool profiling = false;
     struct Ev {
@@ -280,6 +284,9 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     (void)hipFree(c->st_in);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
+    (void)hipFree(c->st_batch);
+    for (auto p : c->pinned)
+        if (p) (void)hipHostFree(p);
     (void)hipFree(c->carry);
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -553,6 +560,151 @@ int dcz_decode_block(dcz_ctx* c, const uint8_t* comp, size_t comp_size, const in
     }
     HIPCHK(c, hipMemcpy(out, c->st_out, out_size, hipMemcpyDeviceToHost));
     return launch_check(c);
+}
+
+/* ---- batched host-pointer twins (what a host-language service calls once per batch of chunks) ---- */
+
+namespace {
+// device columns of one batch of K chunks, carved from c->st_batch
+struct BatchCols {
+    uint32_t* comp_size;
+    uint64_t* comp_off;
+    uint32_t* orig_size;
+    int32_t* status;
+    int64_t* errpos;
+    uint64_t* total;
+    uint8_t* len;
+    uint8_t* sha;
+};
+size_t batch_bytes(size_t K) { return K * (4 + 8 + 4 + 4 + 8 + 256 + 32) + 64; }
+BatchCols batch_at(uint8_t* p, size_t K) {
+    BatchCols b;
+    b.comp_off = reinterpret_cast<uint64_t*>(p);
+    b.errpos = reinterpret_cast<int64_t*>(p + 8 * K);
+    b.total = reinterpret_cast<uint64_t*>(p + 16 * K);
+    b.comp_size = reinterpret_cast<uint32_t*>(p + 16 * K + 16);
+    b.orig_size = b.comp_size + K;
+    b.status = reinterpret_cast<int32_t*>(b.orig_size + K);
+    b.len = reinterpret_cast<uint8_t*>(b.status + K);
+    b.sha = b.len + 256 * K;
+    return b;
+}
+int reserve_batch(dcz_ctx* c, size_t K) {
+    if (K <= c->st_batch_K && c->st_batch) return DCZ_OK;
+    if (c->st_batch) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->st_batch));
+    }
+    c->st_batch = nullptr;
+    c->st_batch_K = 0;
+    const size_t nk = K + K / 8 + 64;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->st_batch), batch_bytes(nk)));
+    c->st_batch_K = nk;
+    return DCZ_OK;
+}
+}  // namespace
+
+int dcz_host_register(void* p, size_t n) {
+    if (!p || !n) return DCZ_E_INVALID;
+    return hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess ? DCZ_OK : DCZ_E_HIP;
+}
+
+int dcz_host_unregister(void* p) {
+    if (!p) return DCZ_E_INVALID;
+    return hipHostUnregister(p) == hipSuccess ? DCZ_OK : DCZ_E_HIP;
+}
+
+void* dcz_ctx_pinned(dcz_ctx* c, int slot, size_t bytes) {
+    if (!c || slot < 0 || slot > 1) return nullptr;
+    if (bytes <= c->pinned_cap[slot] && c->pinned[slot]) return c->pinned[slot];
+    DeviceGuard dg(c->device);
+    (void)hipStreamSynchronize(c->stream);  // (a copy from the old buffer may still be in flight)
+    if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
+    c->pinned[slot] = nullptr;
+    c->pinned_cap[slot] = 0;
+    const size_t cap = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&c->pinned[slot], cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->pinned_cap[slot] = cap;
+    return c->pinned[slot];
+}
+
+int dcz_compress_host(dcz_ctx* c, const uint8_t* in, size_t n, size_t block_bytes, uint8_t* out, size_t out_cap,
+                      uint32_t* comp_size, uint64_t* comp_off, uint8_t* len, int32_t* status, uint64_t* total,
+                      uint8_t* sha256) {
+    if (!c || (!in && n) || !comp_size || !comp_off || !len || !status || (!out && out_cap)) return DCZ_E_INVALID;
+    Geometry g;
+    int r = geometry(n, block_bytes, &g);
+    if (r != DCZ_OK) return r;
+    if (total) *total = 0;
+    if (g.K == 0) return DCZ_OK;
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    const size_t K = g.K;
+    if ((r = grow(c, &c->st_in, &c->st_in_cap, n + 16)) != DCZ_OK) return r;
+    if ((r = grow(c, &c->st_out, &c->st_out_cap, n + 16)) != DCZ_OK) return r;
+    if ((r = reserve_batch(c, K)) != DCZ_OK) return r;
+    const BatchCols b = batch_at(c->st_batch, c->st_batch_K);
+    HIPCHK(c, hipMemcpyAsync(c->st_in, in, n, hipMemcpyHostToDevice, s));
+    if (sha256) launch_sha256(c->st_in, n, block_bytes, g.K, b.sha, s);  // ChecksumUtil.computeSha256 per chunk (K5)
+    r = dcz_compress_blocks(c, c->st_in, n, block_bytes, c->st_out, n, b.comp_size, b.comp_off, b.len, b.status, b.total, s);
+    if (r != DCZ_OK) return r;
+    uint64_t tot = 0;
+    HIPCHK(c, hipMemcpyAsync(comp_size, b.comp_size, 4 * K, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(comp_off, b.comp_off, 8 * K, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(len, b.len, 256 * K, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(status, b.status, 4 * K, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&tot, b.total, 8, hipMemcpyDeviceToHost, s));
+    if (sha256) HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (total) *total = tot;
+    for (size_t k = 0; k < K; k++)
+        if (status[k] != DCZ_OK) return status[k];
+    if (tot > out_cap) return DCZ_E_CAPACITY;
+    if (tot) HIPCHK(c, hipMemcpyAsync(out, c->st_out, tot, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return launch_check(c);
+}
+
+int dcz_decompress_host(dcz_ctx* c, const uint8_t* comp, size_t comp_bytes, const uint64_t* comp_off,
+                        const uint32_t* comp_size, const uint32_t* orig_size, const uint8_t* len, size_t K,
+                        size_t out_stride, uint8_t* out, int32_t* status, int64_t* errpos, uint8_t* sha256) {
+    if (!c || (!comp && comp_bytes) || !comp_off || !comp_size || !orig_size || !len || !status) return DCZ_E_INVALID;
+    if (K == 0) return DCZ_OK;
+    if (!out || K > 0x7FFFFFFFull) return DCZ_E_INVALID;
+    size_t last = 0;  // bytes of the output range that hold chunks: (K - 1) strides + the last chunk
+    for (size_t k = 0; k < K; k++) {
+        if (orig_size[k] > out_stride) return DCZ_E_INVALID;
+        if (orig_size[k]) last = k * out_stride + orig_size[k];
+    }
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    int r;
+    if ((r = grow(c, &c->st_in, &c->st_in_cap, comp_bytes + 32)) != DCZ_OK) return r;
+    if ((r = grow(c, &c->st_out, &c->st_out_cap, K * out_stride + 16)) != DCZ_OK) return r;
+    if ((r = reserve_batch(c, K)) != DCZ_OK) return r;
+    const BatchCols b = batch_at(c->st_batch, c->st_batch_K);
+    if (comp_bytes) HIPCHK(c, hipMemcpyAsync(c->st_in, comp, comp_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(b.comp_off, comp_off, 8 * K, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(b.comp_size, comp_size, 4 * K, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(b.orig_size, orig_size, 4 * K, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(b.len, len, 256 * K, hipMemcpyHostToDevice, s));
+    r = dcz_decompress_blocks(c, c->st_in, comp_bytes, b.comp_off, b.comp_size, b.orig_size, b.len, K, out_stride,
+                              c->st_out, b.status, b.errpos, s);
+    if (r != DCZ_OK) return r;
+    // per-chunk digests of the decoded bytes (verification, CpuCompressionService.java:536-550) when the chunks are
+    // contiguous: every chunk but the last fills its stride
+    bool contiguous = sha256 != nullptr;
+    for (size_t k = 0; contiguous && k + 1 < K; k++) contiguous = orig_size[k] == out_stride;
+    if (contiguous) launch_sha256(c->st_out, last, out_stride, (uint32_t)K, b.sha, s);
+    HIPCHK(c, hipMemcpyAsync(status, b.status, 4 * K, hipMemcpyDeviceToHost, s));
+    if (errpos) HIPCHK(c, hipMemcpyAsync(errpos, b.errpos, 8 * K, hipMemcpyDeviceToHost, s));
+    if (contiguous) HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
+    if (last) HIPCHK(c, hipMemcpyAsync(out, c->st_out, last, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    r = launch_check(c);
+    if (r != DCZ_OK) return r;
+    if (sha256 && !contiguous) return 1;  // decoded, digests not computed (ragged strides): the caller hashes on the host
+    return DCZ_OK;
 }
 
 int dcz_ctx_set_profiling(dcz_ctx* c, int on) {

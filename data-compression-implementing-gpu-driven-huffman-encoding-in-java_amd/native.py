@@ -24,7 +24,8 @@ SEGMENT_BYTES = 32768
 SYMBOLS = [
     "dcz_device_count", "dcz_ctx_create", "dcz_ctx_destroy", "dcz_ctx_stream", "dcz_strerror", "dcz_last_error", "dcz_ctx_reserve",
     "dcz_histogram", "dcz_build_codes", "dcz_codes_from_lengths", "dcz_encode_block", "dcz_decode_block",
-    "dcz_compress_blocks", "dcz_decompress_blocks", "dcz_ctx_set_profiling", "dcz_ctx_reset_profiling",
+    "dcz_compress_blocks", "dcz_decompress_blocks", "dcz_host_register", "dcz_host_unregister", "dcz_ctx_pinned",
+    "dcz_compress_host", "dcz_decompress_host", "dcz_ctx_set_profiling", "dcz_ctx_reset_profiling",
     "dcz_ctx_kernel_time", "dcz_sha256_blocks", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
 ]
 
@@ -82,6 +83,16 @@ def lib():
     L.dcz_compress_blocks.restype = i32
     L.dcz_decompress_blocks.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, sz, vp, vp, vp, vp]
     L.dcz_decompress_blocks.restype = i32
+    L.dcz_host_register.argtypes = [vp, sz]
+    L.dcz_host_register.restype = i32
+    L.dcz_host_unregister.argtypes = [vp]
+    L.dcz_host_unregister.restype = i32
+    L.dcz_ctx_pinned.argtypes = [vp, i32, sz]
+    L.dcz_ctx_pinned.restype = vp
+    L.dcz_compress_host.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, vp, vp, C.POINTER(u64), vp]
+    L.dcz_compress_host.restype = i32
+    L.dcz_decompress_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, sz, vp, vp, vp, vp]
+    L.dcz_decompress_host.restype = i32
     L.dcz_ctx_set_profiling.argtypes = [vp, i32]
     L.dcz_ctx_set_profiling.restype = i32
     L.dcz_ctx_reset_profiling.argtypes = [vp]

@@ -59,8 +59,10 @@ void* dcz_ctx_stream(dcz_ctx* ctx);
 const char* dcz_strerror(int status);
 const char* dcz_last_error(const dcz_ctx* ctx);
 
-/* Pre-allocate the device workspace for inputs of up to n bytes in blocks of block_bytes, so that
- * later dcz_compress_blocks / dcz_decompress_blocks calls allocate nothing (hipGraph-capturable). */
+/* Pre-allocate the device workspace (encoder AND decoder) for inputs of up to n bytes in blocks of block_bytes, so
+ * that later dcz_compress_blocks / dcz_decompress_blocks calls allocate nothing and never synchronise with the host:
+ * they can then be captured in a hipGraph (tests/test_gpu_parity.py::test_compress_and_decompress_are_capturable...).
+ * Without it the first call of a larger geometry grows the workspace (one stream synchronisation + hipMalloc). */
 int dcz_ctx_reserve(dcz_ctx* ctx, size_t n, size_t block_bytes);
 
 /* ---- single-block primitives, host pointers ----------------------------------------------- */
@@ -115,12 +117,41 @@ int dcz_compress_blocks(dcz_ctx* ctx, const void* d_in, size_t n, size_t block_b
  *   d_comp       payload bytes; comp_bytes = total size of that buffer
  *   d_comp_off / d_comp_size / d_orig_size / d_len   per-chunk footer fields (K entries)
  *   d_out        chunk k is written at d_out + k * out_stride (originalOffset, CompressionHeader.java:73)
- *   d_status     K x i32  DCZ_OK / DCZ_E_BADSTREAM / DCZ_E_BADTABLE
- *   d_errpos     K x i64  symbol index of the decode error (may be NULL) */
+ *   d_status     K x i32  DCZ_OK / DCZ_E_BADSTREAM / DCZ_E_BADTABLE / DCZ_E_INVALID
+ *   d_errpos     K x i64  symbol index of the decode error (may be NULL)
+ * The footer fields are untrusted: a chunk with comp_off + comp_size > comp_bytes or orig_size > out_stride gets
+ * DCZ_E_INVALID and is neither read nor written.  Alignment: d_len 16 bytes; the payload may start at any byte, but
+ * the 16-byte aligned units that overlap [d_comp, d_comp + comp_bytes) must be readable (hipMalloc'ed buffers are;
+ * a sub-range of a larger buffer is).  Asynchronous on `stream`; after dcz_ctx_reserve no host synchronisation and no
+ * allocation.  With fewer than 128 chunks of >= 256 KiB of payload on average a chunk is decoded by many workgroups
+ * (csrc/k4_split.hip), so a single 16-32 MiB chunk -- the reference's own chunk sizes -- uses the whole chip. */
 int dcz_decompress_blocks(dcz_ctx* ctx, const void* d_comp, size_t comp_bytes, const uint64_t* d_comp_off,
                           const uint32_t* d_comp_size, const uint32_t* d_orig_size, const uint8_t* d_len,
                           size_t K, size_t out_stride, void* d_out, int32_t* d_status, int64_t* d_errpos,
                           void* stream);
+
+/* ---- batched pipeline on host buffers (one call per batch of chunks; the JNI twins bind these) ---- */
+
+/* Page-lock a caller-owned host range (a direct ByteBuffer) so that the copies below run at full PCIe rate. */
+int dcz_host_register(void* p, size_t n);
+int dcz_host_unregister(void* p);
+/* Library-owned pinned staging (grow-only, slot 0 or 1), for callers whose bytes live in movable memory (byte[]). */
+void* dcz_ctx_pinned(dcz_ctx* ctx, int slot, size_t bytes);
+
+/* dcz_compress_blocks for n bytes in host memory: H2D, K1-K3 (and K5 when sha256 != NULL: 32 bytes per chunk,
+ * ChecksumUtil.computeSha256, util/ChecksumUtil.java:11-27), D2H of the footer columns and the payload.  Everything in
+ * host memory; comp_size / comp_off / len / status as in dcz_compress_blocks.  Synchronous.  Returns the first failing
+ * chunk's status, DCZ_E_CAPACITY if the payload exceeds out_cap. */
+int dcz_compress_host(dcz_ctx* ctx, const uint8_t* in, size_t n, size_t block_bytes, uint8_t* out, size_t out_cap,
+                      uint32_t* comp_size, uint64_t* comp_off, uint8_t* len, int32_t* status, uint64_t* total,
+                      uint8_t* sha256);
+
+/* dcz_decompress_blocks for payloads in host memory; chunk k is written at out + k * out_stride.  sha256 != NULL asks
+ * for the digests of the decoded chunks (computed on the device when every chunk but the last fills its stride;
+ * otherwise the call returns 1 = decoded, digests not computed).  Per-chunk status / errpos as in dcz_decompress_blocks. */
+int dcz_decompress_host(dcz_ctx* ctx, const uint8_t* comp, size_t comp_bytes, const uint64_t* comp_off,
+                        const uint32_t* comp_size, const uint32_t* orig_size, const uint8_t* len, size_t K,
+                        size_t out_stride, uint8_t* out, int32_t* status, int64_t* errpos, uint8_t* sha256);
 
 /* ---- measurement hooks --------------------------------------------------------------------- */
 

@@ -1093,3 +1093,81 @@ def test_split_decode_falls_back_on_damaged_and_foreign_streams(pkg, svc, orc):
             assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
         else:
             assert (out[k * stride:k * stride + want_n] == wdata).all(), "block %d decodes differently" % k
+
+
+def test_compress_and_decompress_are_capturable_in_a_hip_graph(pkg, svc, orc):
+    """include/dcz.h: after dcz_ctx_reserve the batched entry points allocate nothing and never synchronise with the host,
+    so a compress + decompress pair can be captured once and replayed on new data (pipelined halves on two streams, the
+    classify / fixed / table-walk launches of the decoder and, with few large chunks, the split decoder included)."""
+    torch = _torch()
+    lib, h = pkg.lib(), svc.ctx.handle
+    for n, bb, fill, seed in [(2048 * 32768, 32768, lib.dczu_fill_text, 11), (3 * (8 << 20), 8 << 20, lib.dczu_fill_text, 12),
+                              (2048 * 32768, 32768, lib.dczu_fill_java_random, 13)]:
+        K = n // bb
+        svc.ctx.check(lib.dcz_ctx_reserve(h, n, bb))
+        t = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert fill(h, t.data_ptr(), n, seed, 0, None) == 0
+        blk = svc.compress_device(t, bb)  # allocates the outputs (and warms every kernel up)
+        orig = torch.full((K,), bb, dtype=torch.int32, device="cuda")
+        out, st, ep = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            svc.compress_device(t, bb, out=blk, stream=s.cuda_stream)
+            svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb, t_out=out, status=st,
+                                  errpos=ep, stream=s.cuda_stream)
+        for rep in range(2):  # new input, replay only
+            assert fill(h, t.data_ptr(), n, seed + 100 + rep, 0, None) == 0
+            out.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(blk.status.abs().sum()) == 0 and int(st.abs().sum()) == 0
+            assert torch.equal(out[:n], t), "graph replay did not reproduce the new input"
+        data = t[:bb].cpu().numpy()
+        if bb <= (1 << 20):
+            pay, lens = orc.encode_block(data)
+            assert (blk.payload[:int(blk.comp_size[0])].cpu().numpy() == pay).all()
+
+
+def test_host_batch_entry_points_match_the_oracle(pkg, svc, orc):
+    """dcz_compress_host / dcz_decompress_host (what the JNI twins bind): footer columns, payload bytes and per-chunk
+    SHA-256 against the oracle and hashlib, round trip through pinned and registered host buffers."""
+    lib, h = pkg.lib(), svc.ctx.handle
+    for n, bb, gen in [(10 * 65536 + 777, 65536, lambda n: orc.gen_text(4, 0, n)), (3 << 20, 1 << 20, lambda n: orc.java_random_bytes(7, n)),
+                       (5 * 100000 + 1, 100000, lambda n: orc.gen_lowentropy(9, 0, n)), ((8 << 20) + 5, 8 << 20, lambda n: orc.gen_text(5, 0, n))]:
+        data = np.ascontiguousarray(gen(n))
+        K = (n + bb - 1) // bb
+        p_in = lib.dcz_ctx_pinned(h, 0, n)
+        assert p_in
+        C.memmove(p_in, data.ctypes.data, n)
+        out = np.zeros(n + 16, np.uint8)
+        assert lib.dcz_host_register(out.ctypes.data, out.nbytes) == 0
+        sizes, offs = np.zeros(K, np.uint32), np.zeros(K, np.uint64)
+        lens, status, sha = np.zeros((K, 256), np.uint8), np.zeros(K, np.int32), np.zeros((K, 32), np.uint8)
+        total = C.c_uint64()
+        st = lib.dcz_compress_host(h, p_in, n, bb, out.ctypes.data, n, sizes.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                   status.ctypes.data, C.byref(total), sha.ctypes.data)
+        assert st == 0 and (status == 0).all()
+        opay, osizes, ooffs, olens = orc.compress_blocks(data, bb)
+        assert total.value == opay.size and (sizes == osizes).all() and (offs == ooffs).all()
+        assert (lens.astype(np.int32) == olens).all() and (out[:opay.size] == opay).all()
+        for k in range(K):
+            assert sha[k].tobytes() == hashlib.sha256(data[k * bb:(k + 1) * bb].tobytes()).digest()
+        # and back
+        origs = np.array([min(bb, n - k * bb) for k in range(K)], np.uint32)
+        dec = np.zeros(K * bb, np.uint8)
+        dst, dep, dsha = np.zeros(K, np.int32), np.zeros(K, np.int64), np.zeros((K, 32), np.uint8)
+        st = lib.dcz_decompress_host(h, out.ctypes.data, int(total.value), offs.ctypes.data, sizes.ctypes.data,
+                                     origs.ctypes.data, lens.ctypes.data, K, bb, dec.ctypes.data, dst.ctypes.data,
+                                     dep.ctypes.data, dsha.ctypes.data)
+        assert st == 0 and (dst == 0).all()
+        assert (dec[:n] == data).all() and (dsha == sha).all()
+        assert lib.dcz_host_unregister(out.ctypes.data) == 0
+    # untrusted columns: an original size beyond the stride is rejected before anything runs
+    bad = origs.copy()
+    bad[0] = bb + 1
+    assert lib.dcz_decompress_host(h, out.ctypes.data, int(total.value), offs.ctypes.data, sizes.ctypes.data,
+                                   bad.ctypes.data, lens.ctypes.data, K, bb, dec.ctypes.data, dst.ctypes.data,
+                                   dep.ctypes.data, None) == pkg.native.DCZ_E_INVALID

@@ -5,7 +5,7 @@ V=$1; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$V -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-sample-mib 0 > $R/gpurun_out/stats_$V.json 2> $R/gpurun_out/stats_$V.err || echo "stats failed"
 cd $R
 cp $(ls gpurun_out/stats_$V/*/*_kernel_stats.csv | head -1) gpurun_out/kernel_stats_$V.csv || echo "no stats csv"
-bash tools/traffic.sh $V > gpurun_out/traffic_$V.txt 2>&1 && python3 tools/mk_traffic.py $V random8g 4 > gpurun_out/traffic_json_$V.txt
+bash tools/traffic.sh $V > gpurun_out/traffic_$V.txt 2>&1 && python3 tools/mk_traffic.py $V random8g 8589934592 1048576 "build $V" > gpurun_out/traffic_json_$V.txt
 bash tools/pmc.sh $V > gpurun_out/pmc_sq_$V.txt 2>&1
 timeout -k 10 600 python bench.py > gpurun_out/bench_random8g_$V.json 2> gpurun_out/bench_random8g_$V.err || echo "bench default failed"
 for w in random256m text lowentropy; do timeout -k 10 300 python bench.py --workload $w --cpu-sample-mib 0 > gpurun_out/bench_${w}_$V.json 2>/dev/null || echo "bench $w failed"; done
