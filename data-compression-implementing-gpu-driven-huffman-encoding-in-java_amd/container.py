@@ -113,7 +113,10 @@ def locate_header(data):
         probe[:k] = data[:k]
         h = CompressionHeader.read(probe, 0)
         # header-first ("old") format: compressedDataStart = fileSize - sum(compressedSize)  (:349-353)
-        return h, size - sum(c.compressed_size for c in h.chunks)
+        total = sum(c.compressed_size for c in h.chunks)
+        if total > size:
+            raise IOError("compressed sizes exceed the file")
+        return h, size - total
     except (IOError, struct.error):
         pass
     if size < 8:

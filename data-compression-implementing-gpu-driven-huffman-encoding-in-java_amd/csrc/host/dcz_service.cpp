@@ -471,6 +471,7 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
             header = CompressionHeader::read(probe.data(), probe.size());
             size_t sum = 0;
             for (auto& c : header.chunks) sum += c.compressedSize;
+            if (sum > total) throw IOError("Invalid file format: compressed sizes exceed the file");
             dataStart = total - sum;
             parsed = true;
         } catch (const IOError&) {
@@ -489,6 +490,14 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
         dataStart = 0;
     }
     metrics_.record("File I/O", now_ns() - t0, 0);
+    // The metadata is untrusted: sizes that cannot belong to this file are rejected before they size any buffer
+    // (the reference is protected by Java's int / byte[] semantics: CompressionHeader.java:71-84).
+    for (auto& c : header.chunks) {
+        if (header.chunkSizeBytes <= 0 || (int64_t)c.originalSize > (int64_t)header.chunkSizeBytes ||
+            (uint64_t)c.compressedSize > total || c.compressedOffset < 0 || (uint64_t)c.compressedOffset > total)
+            throw IOError("Chunk decompression failed: metadata of chunk " + std::to_string(c.chunkIndex) +
+                          " does not fit the file");
+    }
     const size_t numChunks = header.chunks.size();
     const size_t per = std::max<size_t>(1, batchBytes_ / (size_t)std::max(1, header.chunkSizeBytes));
     // capacities of a slot: the largest batch in chunks, compressed bytes and decoded bytes (stride * chunks)

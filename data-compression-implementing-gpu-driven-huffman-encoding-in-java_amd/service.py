@@ -324,6 +324,12 @@ class HipCompressionService:
         header, data_start = fmt.locate_header(data)
         chunks = header.chunks
         num_chunks = len(chunks)
+        # The metadata is untrusted: sizes that cannot belong to this file are rejected before they size any buffer
+        # (the reference is protected by Java's int / byte[] semantics, CompressionHeader.java:71-84).
+        for c in chunks:
+            if (header.chunk_size_bytes <= 0 or not 0 <= c.original_size <= header.chunk_size_bytes
+                    or not 0 <= c.compressed_size <= len(data) or not 0 <= c.compressed_offset <= len(data)):
+                raise IOError("Chunk decompression failed: metadata of chunk %d does not fit the file" % c.chunk_index)
         dev = torch.device("cuda", self.device)
         per = max(1, self.batch_bytes // max(1, header.chunk_size_bytes))
         done = 0
@@ -335,7 +341,7 @@ class HipCompressionService:
             for c, sp in zip(batch, spans):
                 if len(sp) != c.compressed_size:
                     raise IOError("Chunk decompression failed: truncated payload in chunk %d" % c.chunk_index)
-            sizes = np.array([c.compressed_size for c in batch], dtype=np.int64)
+            sizes = np.array([c.compressed_size for c in batch], dtype=np.int64)  # (device columns are read as u32)
             offs = np.zeros(len(batch), dtype=np.int64)
             offs[1:] = np.cumsum(sizes)[:-1]
             blob = np.frombuffer(b"".join(spans) + b"\0" * 16, dtype=np.uint8)

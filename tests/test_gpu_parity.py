@@ -1171,3 +1171,46 @@ def test_host_batch_entry_points_match_the_oracle(pkg, svc, orc):
     assert lib.dcz_decompress_host(h, out.ctypes.data, int(total.value), offs.ctypes.data, sizes.ctypes.data,
                                    bad.ctypes.data, lens.ctypes.data, K, bb, dec.ctypes.data, dst.ctypes.data,
                                    dep.ctypes.data, None) == pkg.native.DCZ_E_INVALID
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs 4 and 5 at the size ONE GPU holds when the stream is sharded over eight (8 GiB): K = 2048 chunks,
+# the pipelined two-half compress and the many-blocks decode kernels (the 1 GiB cases above run the few-blocks kernels).
+@pytest.mark.parametrize("kind", ["lowentropy", "text"])
+def test_config4_5_at_8gib_per_gpu(pkg, svc, orc, kind):
+    torch = _torch()
+    n, bb = 8 << 30, 4 << 20
+    t = _gen_device(pkg, svc, kind, n)
+    blk = _roundtrip_device(svc, t, bb)  # asserts every status and out == in over all 8 GiB
+    K = blk.num_chunks
+    assert K == 2048
+    sizes = blk.comp_size.to(torch.int64)
+    assert torch.equal(blk.comp_off, torch.cumsum(sizes, 0) - sizes) and int(blk.total.item()) == int(sizes.sum().item())
+    for k in (0, K // 2 - 1, K // 2, K - 1):  # both halves of the pipelined compress, first and last block of each
+        chunk = t[k * bb:(k + 1) * bb]
+        hist = torch.bincount(chunk.to(torch.int64), minlength=256)
+        bits = int((hist * blk.code_lengths[k].to(torch.int64)).sum().item())
+        assert int(blk.comp_size[k].item()) == (bits + 7) // 8
+    for k in (0, K - 1):  # bit-exact against the oracle encoder
+        op, ol = orc.encode_block(t[k * bb:(k + 1) * bb].cpu().numpy())
+        off, sz = int(blk.comp_off[k].item()), int(blk.comp_size[k].item())
+        assert sz == op.size and (blk.code_lengths[k].cpu().numpy() == ol).all()
+        assert (blk.payload[off:off + sz].cpu().numpy() == op).all()
+    ratio = int(blk.total.item()) / n
+    assert (0.55 < ratio < 0.70) if kind == "text" else (0.125 < ratio < 0.15)
+    del blk, t
+    torch.cuda.empty_cache()
+
+
+def test_north_star_8gib_uniform_random_1mib_chunks(pkg, svc, orc):
+    """The north-star workload at full size: every chunk has 256 codes of 8 bits, the payload is the input (K3's copy
+    path), the decoder's fixed-length class reproduces it (k4_fixed)."""
+    torch = _torch()
+    n, bb = 8 << 30, 1 << 20
+    t = _gen_device(pkg, svc, "random", n)
+    blk = _roundtrip_device(svc, t, bb)
+    assert blk.num_chunks == 8192 and bool((blk.code_lengths == 8).all().item())
+    assert int(blk.total.item()) == n and torch.equal(blk.payload[:n], t)
+    assert (t[:bb].cpu().numpy() == orc.java_random_bytes(42, bb)).all()
+    del blk, t
+    torch.cuda.empty_cache()
