@@ -2,7 +2,9 @@
 #include "dcz_service.h"
 
 #include <hip/hip_runtime_api.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -10,6 +12,9 @@
 #include <cstring>
 #include <fstream>
 #include <atomic>
+#include <exception>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -87,6 +92,15 @@ void StageMetrics::record(const std::string& stage, long long ns, long long byte
     a.ns += ns;
     a.count += 1;
     a.bytes += bytes;
+}
+
+void StageMetrics::merge(const StageMetrics& other) {
+    for (auto& kv : other.acc_) {
+        Acc& a = acc_[kv.first];
+        a.ns += kv.second.ns;
+        a.count += kv.second.count;
+        a.bytes += kv.second.bytes;
+    }
 }
 
 long long StageMetrics::time_ns(const std::string& stage) const {
@@ -279,7 +293,10 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
     if (::stat(inputPath.c_str(), &st) != 0) throw IOError("Cannot stat " + inputPath);
     const int64_t size = st.st_size;
     const int64_t cb = chunkBytes_;
-    const int64_t numChunks = (size + cb - 1) / cb;
+    const int64_t allChunks = (size + cb - 1) / cb;
+    // the chunks this call handles: all of them, or this instance's shard
+    const int64_t firstChunk = shard_ ? std::min(shardFirst_, allChunks) : 0;
+    const int64_t numChunks = shard_ ? std::max<int64_t>(0, std::min(shardCount_, allChunks - firstChunk)) : allChunks;
     std::ifstream fin(inputPath, std::ios::binary);
     std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
     if (!fin || !fout) throw IOError("Cannot open input/output file");
@@ -296,7 +313,8 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
     // device buffers.  While the GPU works on batch i (H2D, K5, K1-K3, D2H of the small arrays -- all asynchronous on
     // the slot's stream), the host finishes batch i-1 (payload D2H, ordered write) and reads batch i+1.
     const int64_t perBatch = std::max<int64_t>(1, (int64_t)batchBytes_ / cb);
-    const size_t slotBytes = (size_t)std::min<int64_t>(size, perBatch * cb);
+    const size_t slotBytes = (size_t)std::min<int64_t>(std::max<int64_t>(0, size - firstChunk * cb), perBatch * cb);
+    fin.seekg((std::streamoff)(firstChunk * cb));
     const size_t slotChunks = (size_t)std::min<int64_t>(numChunks, perBatch);
     struct Slot {
         dcz_ctx* ctx = nullptr;
@@ -377,7 +395,7 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
                 m.originalSize = (uint32_t)std::min<int64_t>(cb, size - ci * cb);
                 m.compressedOffset = compOffset;
                 m.compressedSize = sizes[k];
-                std::memcpy(m.sha256, &digests[(size_t)ci * 32], 32);
+                std::memcpy(m.sha256, &digests[(size_t)(ci - firstChunk) * 32], 32);
                 for (int i = 0; i < 256; i++) m.codeLengths[i] = (int16_t)lens[k * 256 + (size_t)i];
                 header.chunks.push_back(m);
                 compOffset += sizes[k];
@@ -387,10 +405,10 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
             sl.busy = false;
         };
         int which = 0;
-        for (int64_t c0 = 0; c0 < numChunks; c0 += perBatch, which ^= (nslots - 1)) {
+        for (int64_t c0 = firstChunk; c0 < firstChunk + numChunks; c0 += perBatch, which ^= (nslots - 1)) {
             Slot& sl = slots[which];
             finish(sl);  // batch i-2 (same slot) must be out before its buffers are reused; keeps the file order
-            const int64_t c1 = std::min(numChunks, c0 + perBatch);
+            const int64_t c1 = std::min(firstChunk + numChunks, c0 + perBatch);
             sl.c0 = c0;
             sl.K = c1 - c0;
             sl.bytes = std::min<int64_t>(size - c0 * cb, (c1 - c0) * cb);
@@ -431,6 +449,11 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
         throw;
     }
     release();
+    if (shard_) {  // payloads only: the coordinator concatenates the shards and writes the footer
+        shardChunks_ = header.chunks;
+        if (!fout) throw IOError("Cannot write " + outputPath);
+        return;
+    }
     const long long t0 = now_ns();
     sha256(digests.data(), digests.size(), header.globalChecksum);  // digest of digests (:106-109, :126)
     const int64_t footerStart = compOffset;
@@ -443,8 +466,14 @@ void HipCompressionService::compress(const std::string& inputPath, const std::st
     metrics_.record("Header Write", now_ns() - t0, 0);
 }
 
-void HipCompressionService::decodeAll(const std::string& path, const std::function<void(const uint8_t*, size_t)>& sink,
-                                      const Progress& progress, CompressionHeader* header_out) {
+void HipCompressionService::setShard(int64_t firstChunk, int64_t chunkCount) {
+    shard_ = true;
+    shardFirst_ = std::max<int64_t>(0, firstChunk);
+    shardCount_ = std::max<int64_t>(0, chunkCount);
+}
+
+void HipCompressionService::decodeAll(const std::string& path, const ChunkSink& sink, const Progress& progress,
+                                      CompressionHeader* header_out) {
     if (!ctx_) throw IOError("GPU decompression failed: HIP device not available");
     metrics_ = StageMetrics();
     hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -498,12 +527,15 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
             throw IOError("Chunk decompression failed: metadata of chunk " + std::to_string(c.chunkIndex) +
                           " does not fit the file");
     }
-    const size_t numChunks = header.chunks.size();
+    const size_t allChunks = header.chunks.size();
+    const size_t firstChunk = shard_ ? std::min<size_t>((size_t)shardFirst_, allChunks) : 0;
+    const size_t numChunks = shard_ ? std::min<size_t>((size_t)shardCount_, allChunks - firstChunk) : allChunks;
+    const size_t lastChunk = firstChunk + numChunks;  // one past this call's last chunk
     const size_t per = std::max<size_t>(1, batchBytes_ / (size_t)std::max(1, header.chunkSizeBytes));
     // capacities of a slot: the largest batch in chunks, compressed bytes and decoded bytes (stride * chunks)
     size_t capK = 0, capComp = 0, capOut = 0;
-    for (size_t c0 = 0; c0 < numChunks; c0 += per) {
-        const size_t c1 = std::min(numChunks, c0 + per);
+    for (size_t c0 = firstChunk; c0 < lastChunk; c0 += per) {
+        const size_t c1 = std::min(lastChunk, c0 + per);
         size_t comp = 0, stride = 16;
         for (size_t k = c0; k < c1; k++) {
             comp += header.chunks[k].compressedSize;
@@ -599,7 +631,7 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
             metrics_.record("Checksum Verification", now_ns() - t1, (long long)(K * stride));
             t1 = now_ns();
             for (size_t k = 0; k < K; k++) {
-                sink(sl.hout + k * stride, header.chunks[sl.c0 + k].originalSize);
+                sink(sl.hout + k * stride, header.chunks[sl.c0 + k].originalSize, header.chunks[sl.c0 + k]);
                 done++;
                 if (progress) progress((double)done / (double)numChunks);
             }
@@ -607,10 +639,10 @@ void HipCompressionService::decodeAll(const std::string& path, const std::functi
             sl.busy = false;
         };
         int which = 0;
-        for (size_t c0 = 0; c0 < numChunks; c0 += per, which ^= (nslots - 1)) {
+        for (size_t c0 = firstChunk; c0 < lastChunk; c0 += per, which ^= (nslots - 1)) {
             Slot& sl = slots[which];
             finish(sl);
-            const size_t c1 = std::min(numChunks, c0 + per), K = c1 - c0;
+            const size_t c1 = std::min(lastChunk, c0 + per), K = c1 - c0;
             sl.c0 = c0;
             sl.K = K;
             t0 = now_ns();
@@ -686,7 +718,8 @@ void HipCompressionService::decompress(const std::string& inputPath, const std::
                                        const Progress& progress) {
     std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
     if (!fout) throw IOError("Cannot open " + outputPath);
-    decodeAll(inputPath, [&](const uint8_t* p, size_t n) { fout.write(reinterpret_cast<const char*>(p), (std::streamsize)n); },
+    decodeAll(inputPath,
+              [&](const uint8_t* p, size_t n, const ChunkMetadata&) { fout.write(reinterpret_cast<const char*>(p), (std::streamsize)n); },
               progress, nullptr);
     if (!fout) throw IOError("Cannot write " + outputPath);
 }
@@ -695,7 +728,7 @@ bool HipCompressionService::verifyIntegrity(const std::string& compressedPath) {
     // A real verification (the reference only scans the last 64 KiB for a header: CpuCompressionService.java:652-694).
     try {
         CompressionHeader h;
-        decodeAll(compressedPath, [](const uint8_t*, size_t) {}, {}, &h);
+        decodeAll(compressedPath, [](const uint8_t*, size_t, const ChunkMetadata&) {}, {}, &h);
         std::vector<uint8_t> dig;
         for (auto& c : h.chunks) dig.insert(dig.end(), c.sha256, c.sha256 + 32);
         uint8_t g[32];
@@ -703,6 +736,169 @@ bool HipCompressionService::verifyIntegrity(const std::string& compressedPath) {
         return std::memcmp(g, h.globalChecksum, 32) == 0;
     } catch (const std::exception&) {
         return false;
+    }
+}
+
+// ---- sharded file -> file (one thread, context and pipeline per device) ---------------------------------------------
+std::vector<std::pair<int64_t, int64_t>> planShards(int64_t numChunks, int gpus) {
+    std::vector<std::pair<int64_t, int64_t>> r;
+    if (gpus < 1) gpus = 1;
+    const int64_t per = (numChunks + gpus - 1) / gpus;
+    for (int g = 0; g < gpus; g++) {
+        const int64_t first = std::min<int64_t>(numChunks, (int64_t)g * per);
+        r.emplace_back(first, std::min<int64_t>(per, numChunks - first));
+    }
+    return r;
+}
+
+namespace {
+struct SharedProgress {
+    std::mutex mu;
+    std::vector<double> frac;
+    std::vector<int64_t> weight;
+    const Progress* out = nullptr;
+    void update(size_t r, double p) {
+        if (!out || !*out) return;
+        std::lock_guard<std::mutex> lk(mu);
+        frac[r] = p;
+        double done = 0, all = 0;
+        for (size_t i = 0; i < frac.size(); i++) {
+            done += frac[i] * (double)weight[i];
+            all += (double)weight[i];
+        }
+        (*out)(all > 0 ? done / all : 1.0);  // monotone in [0, 1], one caller at a time
+    }
+};
+
+template <class Fn>
+void run_ranks(size_t n, Fn fn) {
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(n);
+    for (size_t r = 0; r < n; r++)
+        th.emplace_back([&, r] {
+            try {
+                fn(r);
+            } catch (...) {
+                err[r] = std::current_exception();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : err)
+        if (e) std::rethrow_exception(e);
+}
+}  // namespace
+
+void compressSharded(const std::string& inputPath, const std::string& outputPath, int chunkSizeMB, int gpus,
+                     const Progress& progress, StageMetrics* metrics) {
+    if (gpus < 1 || gpus > dcz_device_count()) throw IOError("GPU compression failed: " + std::to_string(gpus) + " gfx950 devices are not available");
+    struct stat st;
+    if (::stat(inputPath.c_str(), &st) != 0) throw IOError("Cannot stat " + inputPath);
+    const int64_t size = st.st_size, cb = (int64_t)chunkSizeMB * 1024 * 1024;
+    const int64_t numChunks = (size + cb - 1) / cb;
+    const auto plan = planShards(numChunks, gpus);
+    std::vector<std::unique_ptr<HipCompressionService>> svc(plan.size());
+    SharedProgress sp;
+    sp.frac.assign(plan.size(), 0.0);
+    for (auto& pr : plan) sp.weight.push_back(pr.second);
+    sp.out = &progress;
+    auto part = [&](size_t r) { return outputPath + ".part" + std::to_string(r); };
+    try {
+        run_ranks(plan.size(), [&](size_t r) {
+            svc[r].reset(new HipCompressionService(chunkSizeMB, (int)r));
+            if (!svc[r]->isAvailable()) throw IOError("GPU compression failed: device " + std::to_string(r) + " not available");
+            svc[r]->setShard(plan[r].first, plan[r].second);
+            svc[r]->compress(inputPath, part(r), [&, r](double p) { sp.update(r, p); });
+        });
+        // the exchange step: every rank's per-chunk sizes, in rank order -> compressedOffset column and write bases
+        const long long t0 = now_ns();
+        CompressionHeader header;
+        header.originalFileName = base_name(inputPath);
+        header.originalFileSize = size;
+        header.originalTimestamp = (int64_t)st.st_mtim.tv_sec * 1000 + st.st_mtim.tv_nsec / 1000000;
+        header.chunkSizeBytes = (int32_t)cb;
+        std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
+        if (!fout) throw IOError("Cannot open " + outputPath);
+        int64_t base = 0;
+        std::vector<uint8_t> digests, buf((size_t)8 << 20);
+        for (size_t r = 0; r < plan.size(); r++) {
+            int64_t mine = 0;
+            for (ChunkMetadata c : svc[r]->shardChunks()) {
+                mine += c.compressedSize;
+                c.compressedOffset += base;
+                digests.insert(digests.end(), c.sha256, c.sha256 + 32);
+                header.chunks.push_back(c);
+            }
+            std::ifstream pin(part(r), std::ios::binary);
+            int64_t left = mine;
+            while (left > 0) {
+                const std::streamsize n = (std::streamsize)std::min<int64_t>(left, (int64_t)buf.size());
+                if (!pin.read(reinterpret_cast<char*>(buf.data()), n)) throw IOError("Cannot read " + part(r));
+                fout.write(reinterpret_cast<const char*>(buf.data()), n);
+                left -= n;
+            }
+            base += mine;
+        }
+        sha256(digests.data(), digests.size(), header.globalChecksum);
+        const std::vector<uint8_t> hb = header.write();
+        fout.write(reinterpret_cast<const char*>(hb.data()), (std::streamsize)hb.size());
+        BeWriter ptr;
+        ptr.i64(base);
+        fout.write(reinterpret_cast<const char*>(ptr.b.data()), 8);
+        if (!fout) throw IOError("Cannot write " + outputPath);
+        if (metrics) {
+            *metrics = StageMetrics();
+            for (auto& s : svc) metrics->merge(s->getLastStageMetrics());
+            metrics->record("Header Write", now_ns() - t0, 0);
+        }
+    } catch (...) {
+        for (size_t r = 0; r < plan.size(); r++) std::remove(part(r).c_str());
+        throw;
+    }
+    for (size_t r = 0; r < plan.size(); r++) std::remove(part(r).c_str());
+}
+
+void decompressSharded(const std::string& inputPath, const std::string& outputPath, int gpus, const Progress& progress,
+                       StageMetrics* metrics) {
+    if (gpus < 1 || gpus > dcz_device_count()) throw IOError("GPU decompression failed: " + std::to_string(gpus) + " gfx950 devices are not available");
+    // the footer tells every rank its chunks, their payload offsets and where their bytes go: no exchange step
+    CompressionHeader header;
+    {
+        HipCompressionService probe(1, 0);
+        probe.setShard(0, 0);
+        probe.decodeAll(inputPath, [](const uint8_t*, size_t, const ChunkMetadata&) {}, {}, &header);
+    }
+    const auto plan = planShards((int64_t)header.chunks.size(), gpus);
+    const int fd = ::open(outputPath.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) throw IOError("Cannot open " + outputPath);
+    std::vector<std::unique_ptr<HipCompressionService>> svc(plan.size());
+    SharedProgress sp;
+    sp.frac.assign(plan.size(), 0.0);
+    for (auto& pr : plan) sp.weight.push_back(pr.second);
+    sp.out = &progress;
+    try {
+        run_ranks(plan.size(), [&](size_t r) {
+            svc[r].reset(new HipCompressionService(1, (int)r));
+            if (!svc[r]->isAvailable()) throw IOError("GPU decompression failed: device " + std::to_string(r) + " not available");
+            svc[r]->setShard(plan[r].first, plan[r].second);
+            svc[r]->decodeAll(inputPath,
+                              [&](const uint8_t* p, size_t n, const ChunkMetadata& c) {
+                                  size_t off = 0;
+                                  while (off < n) {
+                                      const ssize_t w = ::pwrite(fd, p + off, n - off, (off_t)(c.originalOffset + (int64_t)off));
+                                      if (w <= 0) throw IOError("Cannot write " + outputPath);
+                                      off += (size_t)w;
+                                  }
+                              },
+                              [&, r](double p) { sp.update(r, p); }, nullptr);
+        });
+    } catch (...) {
+        ::close(fd);
+        throw;
+    }
+    if (::close(fd) != 0) throw IOError("Cannot write " + outputPath);
+    if (metrics) {
+        *metrics = StageMetrics();
+        for (auto& s : svc) metrics->merge(s->getLastStageMetrics());
     }
 }
 

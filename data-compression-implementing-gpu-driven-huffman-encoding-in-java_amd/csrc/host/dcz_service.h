@@ -31,6 +31,7 @@ using Progress = std::function<void(double)>;  // Consumer<Double>, may be empty
 class StageMetrics {
   public:
     void record(const std::string& stage, long long ns, long long bytes = 0);
+    void merge(const StageMetrics& other);  // sums another service's accumulators into this one (sharded runs)
     std::string summary() const;
     long long time_ns(const std::string& stage) const;
 
@@ -94,14 +95,34 @@ class HipCompressionService {
     void close();
     const StageMetrics& getLastStageMetrics() const { return metrics_; }
 
+    // Shard mode (multi-GPU): this instance handles the chunks [first, first + count) of the file only.
+    // compress() then writes just the payloads of its range to outputPath (no footer) and keeps their metadata, with
+    // compressedOffset counted from its own first payload byte; decompress-side calls hand only those chunks to the sink.
+    void setShard(int64_t firstChunk, int64_t chunkCount);
+    const std::vector<ChunkMetadata>& shardChunks() const { return shardChunks_; }
+    using ChunkSink = std::function<void(const uint8_t*, size_t, const ChunkMetadata&)>;
+    void decodeAll(const std::string& path, const ChunkSink& sink, const Progress& progress, CompressionHeader* header_out);
+
   private:
-    void decodeAll(const std::string& path, const std::function<void(const uint8_t*, size_t)>& sink,
-                   const Progress& progress, CompressionHeader* header_out);
+    bool shard_ = false;
+    int64_t shardFirst_ = 0, shardCount_ = 0;
+    std::vector<ChunkMetadata> shardChunks_;
     dcz_ctx* ctx_ = nullptr;
     int device_ = 0;
     int64_t chunkBytes_ = 0;
     size_t batchBytes_ = (size_t)256 << 20;  // per pipeline slot (two slots: pinned + device buffers of this size)
     StageMetrics metrics_;
 };
+
+// ---- one file over several GPUs of one node -----------------------------------------------------
+// Rank r owns the contiguous chunk range [r * ceil(K / G), min(K, (r + 1) * ceil(K / G))): one thread, one context and one
+// streaming pipeline per device; payload bytes never leave their device's pipeline.  The only exchange is the per-chunk
+// compressedSize column, gathered on the host: an exclusive scan over all chunks gives the footer's compressedOffset
+// column (core/CompressionHeader.java:75) and every rank's base in the file.
+std::vector<std::pair<int64_t, int64_t>> planShards(int64_t numChunks, int gpus);  // (first, count) per rank
+void compressSharded(const std::string& inputPath, const std::string& outputPath, int chunkSizeMB, int gpus,
+                     const Progress& progress = {}, StageMetrics* metrics = nullptr);
+void decompressSharded(const std::string& inputPath, const std::string& outputPath, int gpus, const Progress& progress = {},
+                       StageMetrics* metrics = nullptr);
 
 }  // namespace datacomp

@@ -21,6 +21,9 @@ namespace dcz {
 #ifndef DCZ_K1_COPIES
 #define DCZ_K1_COPIES 16
 #endif
+#ifndef DCZ_K1_NT
+#define DCZ_K1_NT 0  // measured: no difference (K1 is bound by its LDS atomics at ~5.6 TB/s, not by the loads)
+#endif
 #ifndef DCZ_K1_WAVES
 #define DCZ_K1_WAVES 4
 #endif
@@ -88,10 +91,21 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
         const uint32_t i0 = base + (uint32_t)lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
         uint4 d0, d1, d2, d3;
         if (base + 256 <= nvec) {
+#if DCZ_K1_NT
+            // read-once stream: non-temporal loads (copybench: 7.1 TB/s against 6.2-6.3 TB/s for plain loads)
+            const u32x4* pn = reinterpret_cast<const u32x4*>(pv);
+            const u32x4 n0 = __builtin_nontemporal_load(pn + i0), n1 = __builtin_nontemporal_load(pn + i1);
+            const u32x4 n2 = __builtin_nontemporal_load(pn + i2), n3 = __builtin_nontemporal_load(pn + i3);
+            d0 = make_uint4(n0.x, n0.y, n0.z, n0.w);
+            d1 = make_uint4(n1.x, n1.y, n1.z, n1.w);
+            d2 = make_uint4(n2.x, n2.y, n2.z, n2.w);
+            d3 = make_uint4(n3.x, n3.y, n3.z, n3.w);
+#else
             d0 = pv[i0];
             d1 = pv[i1];
             d2 = pv[i2];
             d3 = pv[i3];
+#endif
             hist_add_vec(h, col, d0);
             hist_add_vec(h, col, d1);
             hist_add_vec(h, col, d2);

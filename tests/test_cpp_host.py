@@ -102,3 +102,63 @@ def test_cli_streams_many_batches_through_both_pipeline_slots(svc, orc, pkg, tmp
     (tmp_path / "bad.dcz").write_bytes(bytes(bad))
     r = run("decompress", tmp_path / "bad.dcz", tmp_path / "bad.out")
     assert r.returncode == 1 and ("Checksum mismatch in chunk" in r.stderr or "Huffman decode error at position" in r.stderr)
+
+
+def test_shard_plan_matches_the_python_sharding_rule():
+    """`dczcli shardplan K G` (pure host logic, no GPU): rank r owns [r * ceil(K/G), min(K, (r+1) * ceil(K/G))) -- the
+    same ranges sharding.chunk_range gives torch.distributed ranks; ranges tile [0, K) in order."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.load_package()
+    from dcz_amd import sharding
+    for K, G in [(2048, 8), (16384, 8), (10, 4), (3, 8), (0, 2), (7, 1), (257, 2)]:
+        r = run("shardplan", K, G)
+        assert r.returncode == 0, r.stderr
+        got = [tuple(map(int, line.split())) for line in r.stdout.strip().splitlines()]
+        want = []
+        for rank in range(G):
+            first, last = sharding.chunk_range(K, G, rank)
+            want.append((first, last - first))
+        assert got == want
+        assert sum(c for _, c in got) == K
+        pos = 0
+        for first, cnt in got:
+            assert first == min(pos, K) or cnt == 0
+            pos += cnt
+
+
+@pytest.mark.gpu
+def test_cli_sharded_path_on_one_gpu_writes_the_same_container(svc, orc, pkg, tmp_path, monkeypatch):
+    """--gpus 1 goes through the multi-GPU code path (shard pipeline per device, payload parts concatenated, offsets from
+    the gathered sizes, footer written by the coordinator): the container must be byte-identical to the classic path's,
+    and the sharded decompressor (pwrite at originalOffset) must reproduce the input."""
+    data = np.concatenate([orc.gen_text(5, 0, 6_300_000), orc.java_random_bytes(5, 2_100_001)])
+    src = tmp_path / "in.bin"
+    src.write_bytes(data.tobytes())
+    monkeypatch.setenv("DCZ_BATCH_MB", "2")  # several batches per shard
+    assert run("compress", src, tmp_path / "classic.dcz", 1).returncode == 0
+    r = run("compress", src, tmp_path / "sharded.dcz", 1, "--gpus", 1)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "sharded.dcz").read_bytes() == (tmp_path / "classic.dcz").read_bytes()
+    assert not list(tmp_path.glob("*.part*"))
+    r = run("d", tmp_path / "classic.dcz", tmp_path / "back.bin", "--gpus", 1)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "back.bin").read_bytes() == data.tobytes()
+    # more devices than the box has: refused, nothing written
+    r = run("compress", src, tmp_path / "x.dcz", 1, "--gpus", 64)
+    assert r.returncode == 1 and "devices are not available" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_bench_mirrors_benchmark_suite(orc, tmp_path):
+    """`dczcli bench` = BenchmarkSuite.benchmarkService (benchmark/BenchmarkSuite.java:68-121): 3 warm-ups, 5 timed runs,
+    MB/s = bytes / 1e6 / s; plus the decompress timing and the StageMetrics summaries."""
+    src = tmp_path / "b.bin"
+    src.write_bytes(orc.gen_text(6, 0, 3_000_000).tobytes())
+    r = run("bench", src, 1)
+    assert r.returncode == 0, r.stderr
+    for needle in ("Benchmark complete:", "5 iterations after 3 warm-ups", "compress:", "decompress:", "MB/s",
+                   "Stage Performance Breakdown:", "Encoding", "Decoding"):
+        assert needle in r.stdout, needle
+    assert not (tmp_path / "b.bin.bench.dcz").exists()
