@@ -94,8 +94,10 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #define DCZ_K4_EXIT_EVERY 2  // measured over 3 runs each: 2 is ~1.5 % faster than 1; 4 and 8 are 35-45 % SLOWER
 #endif
 #ifndef DCZ_K4_GROUP
-#define DCZ_K4_GROUP 1
-#endif
+#define DCZ_K4_GROUP 0  // 1: a third copy of the unrolled steps for total tables with codewords <= 8 bits (one window fetch per
+#endif                  // four symbols).  Its main customer -- 256 symbols of 8 bits -- is decoded by k4_fixed.hip now; without
+                        // the copy the long-code instantiation spills 1 VGPR instead of 15 (scratch 16 B instead of 64 B per
+                        // lane) at the same speed on every distribution measured (text, hi7, hi7_5, bin7_8, mid6).
 #ifndef DCZ_K4_EXACT
 #define DCZ_K4_EXACT 1        // exact-entry procedure for windows that do not self-synchronise
 #endif
