@@ -111,6 +111,9 @@ constexpr int SUB_DW = SUB_BYTES / 4;
 #ifndef DCZ_K4S_NS
 #define DCZ_K4S_NS 1
 #endif
+#ifndef DCZ_K4_MEDIUM_DFA
+#define DCZ_K4_MEDIUM_DFA 1  // medium class, one workgroup per block: k4_dfa.hip decodes the tables it can take
+#endif
 #ifndef DCZ_K4_TBS
 #define DCZ_K4_TBS DCZ_K4_TB  // first-level table bits of the short-code (multi-symbol) instantiation
 #endif
@@ -158,6 +161,7 @@ struct DecLds {
     uint32_t maxlen;
     uint32_t nomiss;  // complete code with maxlen <= TB: the 2^TB table has no escape entries
     uint32_t in_phase;  // one code length that divides SUB_BITS: entry offsets are known without decoding
+    uint32_t dfa_takes;  // medium class: the nibble automaton (k4_dfa.hip) decodes this block
     uint32_t err_idx;
     int bad_table;
 };
@@ -459,6 +463,18 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         L.lim[0] = 0;
         for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
+#if DCZ_K4_MEDIUM_DFA
+        if constexpr (CMASK == 2 && MODE == 0) {
+            // blocks the nibble automaton takes (k4_dfa.hip applies the same test to the same table): no 1-bit codeword
+            // and at most 255 internal nodes in the code tree; this kernel keeps the rest of the medium class
+            uint32_t ni = 0, states = 0;
+            for (int l = 31; l >= 0; l--) {
+                ni = (L.cnt[l + 1] + ni + 1u) / 2u;
+                states += ni;
+            }
+            L.dfa_takes = (L.cnt[1] == 0u && states <= 255u && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
+        }
+#endif
         L.nomiss = (mx >= 1u && mx <= (uint32_t)TB && kraft == (1ull << 32)) ? 1u : 0u;
         if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
         // every codeword has the same length and that length divides the subsequence: always in phase
@@ -473,6 +489,11 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         }
         return;
     }
+#if DCZ_K4_MEDIUM_DFA
+    if constexpr (CMASK == 2 && MODE == 0) {
+        if (L.dfa_takes) return;  // workgroup-uniform
+    }
+#endif
     if constexpr (MODE == 2) {
         if (L.in_phase) return;  // the probe has nothing to find out (e.g. 256 symbols of 8 bits)
     }
@@ -1278,6 +1299,9 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 #else
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 0);
 #endif
+#if DCZ_K4_MEDIUM_DFA
+        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, s);
+#endif
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 1);
@@ -1296,6 +1320,9 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
                              ws, true, s);
 #else
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 0);
+#endif
+#if DCZ_K4_MEDIUM_DFA
+        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, s);
 #endif
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT

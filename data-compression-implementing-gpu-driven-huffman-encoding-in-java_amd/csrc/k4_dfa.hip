@@ -1,0 +1,481 @@
+// k4_dfa.hip -- K4 for medium code lengths (3.6 .. 6.5 bits per symbol, e.g. text): nibble automaton (gfx950).
+//
+// Same contract as k4_decode.hip (TableBasedHuffmanDecoder.decode, core/TableBasedHuffmanDecoder.java:103-152 with the
+// fallback of core/CanonicalHuffman.java:161-229; zero bits past the payload :204-208; "decode error at position i"
+// :109-111) and the same outer structure (windows of W subsequences x 32 bytes, self-synchronisation, workgroup scan,
+// LDS tile flushed with aligned 16-byte stores).  What the counters of k4_decode's medium class say
+// (profiles/r02_base_text8g_sq.txt): the kernel is INSTRUCTION-ISSUE bound -- per 64 symbols 33 vector + 14 scalar + 6 LDS
+// instructions, the vector pipe of a SIMD ~60 % busy with four waves -- and a wave runs as long as its slowest lane
+// (70 steps for 52 symbols on average).  This kernel does the same work with fewer, branch-free instructions:
+//   * the decoder is a finite automaton over NIBBLES: state = internal node of the code tree (<= 254 states, root = 0),
+//     T[state][nibble] = next state << 6 | symbols completed inside the nibble (0..2) | their bytes << 16.  Every lane
+//     takes exactly 64 steps per subsequence, whatever the code lengths: no divergence, no ballots, no branches, no
+//     escape path for long codewords (a 21-bit codeword is six ordinary steps), straight-line code;
+//   * the subsequence lives in registers (8 dwords; the nibble of step j is a compile-time bit field) and needs no
+//     look-ahead: a codeword that crosses a subsequence boundary is carried by the STATE, so a subsequence's entry and exit
+//     are automaton states instead of bit offsets and the fixed point "my entry = my left neighbour's exit" is iterated
+//     on states (first one exact; converges like codeword synchronisation does: 2 walks per window on text);
+//   * a walk (phase A) is 5 vector + 1 LDS instruction per step and counts the symbols that COMPLETE inside the
+//     subsequence; the output pass (phase B) is the same walk with two byte stores per step into the tile at the offsets
+//     of the scan.
+// Not handled here (the block is left to k4_decode.hip's medium-class kernel, decided from the length table alone):
+// tables with a 1-bit codeword (a nibble could complete three or four symbols), tables whose code tree has more than 254
+// internal nodes (foreign incomplete tables only).  A window that is not synchronised after DCZ_K4_EXACT_AFTER rounds
+// hands its block to the exact-entry launch, as everywhere.
+#include <cstdlib>
+#include <utility>
+
+#include "dcz_internal.h"
+
+namespace dcz {
+
+#ifndef DCZ_DFA_W
+#define DCZ_DFA_W 256
+#endif
+#ifndef DCZ_DFA_OC
+#define DCZ_DFA_OC 16384  // tile bytes per flush: a whole window of text (13.3 KiB on average) in one flush
+#endif
+#ifndef DCZ_DFA_MINWAVES
+#define DCZ_DFA_MINWAVES 4
+#endif
+#ifndef DCZ_K4_EXACT_AFTER
+#define DCZ_K4_EXACT_AFTER 12
+#endif
+#ifndef DCZ_K4_CLS2_A
+#define DCZ_K4_CLS2_A 4
+#endif
+#ifndef DCZ_K4_CLS2_B
+#define DCZ_K4_CLS2_B 9
+#endif
+
+constexpr uint32_t DFA_ERR = 255;  // sticky state: the stream left the code tree
+
+template <int W, int OC>
+struct DfaLds {
+    static constexpr int CAP = OC + 512;  // tile capacity (the last lane of a flush may run 300 bytes past its end)
+    __attribute__((aligned(16))) uint32_t T[256 * 16];          // [state][nibble]
+    __attribute__((aligned(16))) uint32_t tile[CAP / 4 + 160];  // + slack for the dummy bytes of switched-off lanes
+    uint8_t exits[W];
+    uint8_t node_l[256];   // depth of internal node `id`
+    uint32_t node_p[256];  // its prefix (the l bits that lead to it)
+    uint32_t first[34], cnt[34], offs[34], nint[34], base[34];
+    uint32_t wsum[W / 64];
+    uint32_t flag[3];
+    uint8_t symtab[256], len8[256];
+    uint32_t maxlen, nstates, err_idx, cend_vote;
+    int bad_table;
+};
+
+template <int W, class LdsT>
+__device__ __forceinline__ uint32_t dfa_block_scan(uint32_t v, LdsT& L, uint32_t& total) {
+    const uint32_t inc = wave_inclusive_scan_u32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 63u) L.wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < W / 64; w++) {
+        const uint32_t sv = L.wsum[w];
+        if (w < (int)(threadIdx.x >> 6)) base += sv;
+        tot += sv;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// 16 payload bytes at payload-relative byte `off` (any alignment) from the aligned chunks of the virtual buffer
+template <int Q>
+__device__ __forceinline__ uint4 dfa_shift(const uint4& a, const uint4& b, uint32_t r) {
+    const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return make_uint4(__builtin_amdgcn_alignbyte(d[Q + 1], d[Q], r), __builtin_amdgcn_alignbyte(d[Q + 2], d[Q + 1], r),
+                      __builtin_amdgcn_alignbyte(d[Q + 3], d[Q + 2], r), __builtin_amdgcn_alignbyte(d[Q + 4], d[Q + 3], r));
+}
+
+#if DCZ_K4_PROF
+__device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] flushes
+#define DFA_T(i)                                  \
+    do {                                          \
+        const unsigned long long t_ = clock64();  \
+        pacc[i] += t_ - plast;                    \
+        plast = t_;                               \
+    } while (0)
+#else
+#define DFA_T(i) do { } while (0)
+#endif
+
+template <int W, int OC>
+__global__ __launch_bounds__(W, W <= 256 ? DCZ_DFA_MINWAVES : (W <= 512 ? 2 : 1)) void k4_dfa(
+    const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
+    const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
+    size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
+    uint8_t* __restrict__ d_cls) {
+    using LdsT = DfaLds<W, OC>;
+    __shared__ LdsT L;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    const uint32_t b = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+#if DCZ_K4_PROF
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = clock64();
+#endif
+    if (d_cls[b] != 0) return;  // fixed-length, exact-entry, split or rejected block (workgroup-uniform)
+    const uint32_t orig = d_orig_size[b];
+    const unsigned long long coff = d_comp_off[b];
+    const uint32_t csize = d_comp_size[b];
+    {
+        const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig * 13ull;
+        const bool medium = (unsigned long long)orig * (unsigned long long)DCZ_K4_CLS2_A <=
+                            (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B;
+        if (long_codes || !medium) return;  // workgroup-uniform; other launches own those blocks
+    }
+
+    // ---- per-block tables (rebuildCodes: CpuCompressionService.java:582-586 -> CanonicalHuffman.java:99-132) ----
+    if (tid < 34) L.cnt[tid] = 0;
+    if (tid == 0) {
+        L.bad_table = 0;
+        L.err_idx = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int sy = tid; sy < 256; sy += W) {
+        const uint32_t l = d_len[(uint64_t)b * 256u + sy];
+        L.len8[sy] = (uint8_t)l;
+        if (l > 32) L.bad_table = 1;
+        else if (l > 0) atomicAdd(&L.cnt[l], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0, o = 0, mx = 0;
+        unsigned long long kraft = 0;
+        L.first[0] = 0;
+        L.offs[0] = 0;
+        for (int l = 1; l <= 32; l++) {
+            c = (c + L.cnt[l - 1]) << 1;
+            L.first[l] = c;
+            L.offs[l] = o;
+            o += L.cnt[l];
+            if (L.cnt[l]) mx = (uint32_t)l;
+            kraft += (unsigned long long)L.cnt[l] << (32 - l);
+        }
+        L.maxlen = mx;
+        if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
+        // internal nodes per depth: the prefixes of the longer codewords follow the leaves of a depth contiguously
+        // (canonical code), so nint[l] = ceil((cnt[l+1] + nint[l+1]) / 2); state id = base[l] + index among them
+        L.nint[32] = 0;
+        L.nint[33] = 0;
+        for (int l = 31; l >= 0; l--) L.nint[l] = (L.cnt[l + 1] + L.nint[l + 1] + 1u) / 2u;
+        uint32_t acc = 0;
+        for (int l = 0; l < 34; l++) {
+            L.base[l] = acc;
+            acc += L.nint[l];
+        }
+        L.nstates = acc;
+    }
+    __syncthreads();
+    if (L.bad_table) {
+        if (tid == 0) {
+            d_status[b] = DCZ_E_BADTABLE;
+            if (d_errpos) d_errpos[b] = 0;
+        }
+        return;
+    }
+    // tables this automaton does not take (k4_decode.hip's medium-class kernel applies the same test and decodes them)
+    if (L.cnt[1] != 0u || L.nstates > 255u || L.maxlen == 0u) return;
+    for (int sy = tid; sy < 256; sy += W) {
+        const uint32_t l = L.len8[sy];
+        if (l > 0) {
+            uint32_t rank = 0;
+            for (int t = 0; t < sy; t++) rank += (L.len8[t] == l) ? 1u : 0u;
+            L.symtab[L.offs[l] + rank] = (uint8_t)sy;
+        }
+    }
+    for (uint32_t id = (uint32_t)tid; id < L.nstates; id += W) {  // (depth, prefix) of every internal node
+        uint32_t l = 0;
+        while (l < 33u && id >= L.base[l + 1]) l++;
+        L.node_l[id] = (uint8_t)l;
+        L.node_p[id] = L.first[l] + L.cnt[l] + (id - L.base[l]);
+    }
+    __syncthreads();
+    for (uint32_t idx = (uint32_t)tid; idx < 256u * 16u; idx += W) {
+        const uint32_t st = idx >> 4, nib = idx & 15u;
+        uint32_t e = (DFA_ERR << 6) | 4u;  // unused rows and the error state: stay in the error state
+        if (st < L.nstates) {
+            uint32_t l = L.node_l[st], p = L.node_p[st], c = 0, syms = 0;
+            bool err = false;
+            for (int i = 3; i >= 0 && !err; i--) {
+                p = 2u * p + ((nib >> i) & 1u);
+                l++;
+                if (l > 32u) {
+                    err = true;
+                    break;
+                }
+                const uint32_t rel = p - L.first[l];
+                if (rel < L.cnt[l]) {  // a leaf: the codeword is complete
+                    syms |= (uint32_t)L.symtab[L.offs[l] + rel] << (8 * c);
+                    c++;
+                    l = 0;
+                    p = 0;
+                } else if (rel - L.cnt[l] >= L.nint[l]) {
+                    err = true;  // no codeword has this prefix (incomplete code)
+                }
+            }
+            if (!err) e = ((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (syms << 16);
+        }
+        L.T[idx] = e;
+    }
+    const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.T[0]));
+
+    uint8_t* const oblk = out + (uint64_t)b * out_stride;
+    const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
+    const uintptr_t pay = (uintptr_t)comp + (uintptr_t)coff;
+    const uint32_t skew = (uint32_t)(pay & 15u);
+    const uint8_t* const vbase = reinterpret_cast<const uint8_t*>(pay - skew);
+    const unsigned long long vlo = skew, vhi = (unsigned long long)skew + csize;
+    const uint32_t sq = skew >> 2, sr = skew & 3u;
+
+    uint32_t produced = 0, gpos = 0, ocarry = 0;
+    uint32_t entry0 = 0;  // state at the first nibble of the window (the block starts at the root)
+    unsigned long long wbyte = 0;  // payload byte of the window's first subsequence
+    int status = DCZ_OK;
+    long long errpos = 0;
+    uint8_t* const ob = reinterpret_cast<uint8_t*>(L.tile);
+    constexpr uint32_t DUMMY = (uint32_t)LdsT::CAP + 320u;  // tile bytes nobody flushes
+
+    // this lane's 32 payload bytes of the window at `wb`: three aligned chunks, shifted by the payload's skew
+    uint4 pre[3];
+    auto prefetch = [&](unsigned long long wb) {
+        const unsigned long long v0 = (wb + 32ull * (unsigned long long)tid + skew) & ~15ull;
+#pragma unroll
+        for (int c = 0; c < 3; c++) pre[c] = load_chunk16(vbase, v0 + 16ull * c, vlo, vhi);
+    };
+    if (orig > 0) prefetch(0);
+    __syncthreads();  // T complete
+    DFA_T(0);
+
+    while (produced < orig) {
+#if DCZ_K4_PROF
+        pacc[8]++;
+#endif
+        uint32_t R[8];
+        {
+            uint4 lo, hi;
+            switch (sq) {  // block-uniform
+                case 0: lo = dfa_shift<0>(pre[0], pre[1], sr); hi = dfa_shift<0>(pre[1], pre[2], sr); break;
+                case 1: lo = dfa_shift<1>(pre[0], pre[1], sr); hi = dfa_shift<1>(pre[1], pre[2], sr); break;
+                case 2: lo = dfa_shift<2>(pre[0], pre[1], sr); hi = dfa_shift<2>(pre[1], pre[2], sr); break;
+                default: lo = dfa_shift<3>(pre[0], pre[1], sr); hi = dfa_shift<3>(pre[1], pre[2], sr); break;
+            }
+            R[0] = bswap32(lo.x);
+            R[1] = bswap32(lo.y);
+            R[2] = bswap32(lo.z);
+            R[3] = bswap32(lo.w);
+            R[4] = bswap32(hi.x);
+            R[5] = bswap32(hi.y);
+            R[6] = bswap32(hi.z);
+            R[7] = bswap32(hi.w);
+        }
+        DFA_T(1);
+        // Subsequences that START past the payload hold nothing but zero padding: they take no part; the symbols the
+        // reference would read from the padding are filled in after the window (see "exhausted").
+        const bool exhausted = wbyte + (unsigned long long)W * 32ull >= csize;
+        const bool beyond = wbyte + 32ull * (unsigned long long)tid >= csize;
+        const bool more_payload = !exhausted;
+        if (more_payload) prefetch(wbyte + (unsigned long long)W * 32ull);  // the window grid is fixed: load ahead
+
+        // ---- phase A: fixed point of "my entry state = my left neighbour's exit state" ----
+        // Round 0 walks every subsequence from the guess "at a codeword boundary" and only wants its exit state; round 1
+        // walks every subsequence again from its neighbour's exit and counts the symbols that complete inside it (a wave
+        // walks as long as any of its lanes does, so lanes whose guess was right cost nothing extra and get their count
+        // here too); later rounds (rare) re-walk the lanes whose entry still changed.
+        uint32_t g = (tid == 0) ? entry0 : 0u;  // entry state
+        uint32_t x = 0, nsym = 0;
+        bool need = !beyond;
+        uint32_t round = 0;
+        while (true) {
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
+                uint32_t e = g << 6, n = 0;
+                if (round == 0u) {  // workgroup-uniform
+                    auto stepX = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sh = 26 - 4 * (j & 7);  // nibble j of the dword, as a byte offset of a u32 entry
+                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepX(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64>{});
+                } else {
+                    auto stepA = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sh = 26 - 4 * (j & 7);
+                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
+                        n += e & 3u;
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepA(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64>{});
+                }
+                if (need) {
+                    x = (e >> 6) & 0xFFu;
+                    nsym = n;
+                }
+            }
+            DFA_T(2);
+#if DCZ_K4_PROF
+            pacc[9]++;
+#endif
+            L.exits[tid] = (uint8_t)x;
+            if (tid == 0) L.flag[(round + 1u) % 3u] = 0;
+            __syncthreads();
+            DFA_T(3);
+            if (round > 1u && L.flag[round % 3u] == 0u) break;
+            const uint32_t ng = (tid == 0) ? entry0 : (uint32_t)L.exits[tid - 1];
+            need = ((ng != g) || round == 0u) && !beyond;  // after the exit-only round everybody walks once more
+            g = ng;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
+            round++;
+            if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
+                if (tid == 0) d_cls[b] = 1;                // the exact-entry launch (k4_decode.hip, MODE 1) decodes it
+                return;
+            }
+        }
+
+        // ---- offsets, errors ----
+        const bool bad = !beyond && x == DFA_ERR;
+        uint32_t tw = 0;
+        const uint32_t o = dfa_block_scan<W>(nsym, L, tw);
+        const uint32_t remaining = orig - produced;
+        if (bad) atomicMin(&L.err_idx, o + nsym);  // (the error state completes no symbol: nsym = symbols before it)
+        const uint32_t next_entry = L.exits[W - 1];
+        __syncthreads();
+        const uint32_t err_idx = L.err_idx;
+        if (err_idx < remaining) {
+            status = DCZ_E_BADSTREAM;
+            errpos = (long long)produced + (long long)err_idx;
+            break;
+        }
+        const uint32_t lim = (tw < remaining) ? tw : remaining;
+        const bool more = produced + lim < orig;
+        DFA_T(4);
+
+        // ---- phase B: the same walk from the final entry state, two byte stores per step ----
+        for (uint32_t cbase = 0; cbase < lim;) {
+            uint32_t cc = lim - cbase;
+            const uint32_t room = (uint32_t)LdsT::CAP - ocarry;
+            if (cc > room) {  // workgroup-uniform: the rest of the window does not fit one flush: end it on a subsequence
+                if (tid == 0) L.cend_vote = 0;
+                __syncthreads();
+                const uint32_t end0 = o + nsym;
+                if (end0 > cbase + room / 2u && end0 <= cbase + room) atomicMax(&L.cend_vote, end0);
+                __syncthreads();
+                const uint32_t v = L.cend_vote;
+                cc = v != 0u ? v - cbase : room;  // (a subsequence completes < 130 symbols: a boundary always exists)
+            }
+            const uint32_t cend = cbase + cc;
+            const uint32_t tshift = ocarry - cbase;  // tile index = window symbol index + tshift
+            // a lane takes part in this flush when its first symbol lies inside it (flushes end on subsequence
+            // boundaries; at the end of the block the last lane may run past `lim` into the tile's slack)
+            const bool mine = nsym > 0u && o >= cbase && o < cend;
+            if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+                uint32_t e = g << 6;
+                uint32_t t = mine ? o + tshift : DUMMY;
+                const uint32_t tmask = mine ? 3u : 0u;  // switched-off lanes do not advance: they store to the dummy bytes
+                auto stepB = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int sh = 26 - 4 * (j & 7);
+                    const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
+                    const uint32_t c = e & tmask;
+                    // (a step that completes nothing must not store: after the lane's last symbol, t is the next
+                    // lane's first byte)
+                    ob[c >= 1u ? t : DUMMY] = (uint8_t)(e >> 16);
+                    (ob + 1)[c >= 2u ? t : DUMMY + 4u] = (uint8_t)(e >> 24);  // the second symbol, if there is one
+                    t += c;
+                };
+                [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                    (stepB(std::integral_constant<int, Js>{}), ...);
+                }(std::make_integer_sequence<int, 64>{});
+            }
+            DFA_T(5);
+#if DCZ_K4_PROF
+            pacc[10]++;
+#endif
+            __syncthreads();
+            DFA_T(6);
+            const uint32_t total = ocarry + cc;
+            const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
+            const uint32_t full = last ? total : (total & ~15u);
+            uint8_t* const dst = oblk + gpos;
+            const uint32_t nunits = (full + 15u) >> 4;
+            for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
+                const uint32_t lo = u << 4;
+                const uint32_t* src = &L.tile[lo >> 2];
+                if (out_aligned && lo + 16u <= full) {
+                    *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
+                } else {
+                    for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[i];
+                }
+            }
+            const uint32_t tail = total - full;  // < 16
+            uint8_t tv = 0;
+            if ((uint32_t)tid < tail) tv = ob[full + tid];
+            __syncthreads();
+            if ((uint32_t)tid < tail) ob[tid] = tv;
+            gpos += full;
+            ocarry = tail;
+            cbase = cend;
+            DFA_T(7);
+        }
+        produced += lim;
+        entry0 = next_entry;
+        wbyte += (unsigned long long)W * 32ull;
+        if (exhausted && produced < orig) {
+            // The payload is used up but the chunk wants more symbols: the reference keeps reading zero bits
+            // (TableBasedHuffmanDecoder.java:204-208), i.e. the all-zero codeword = first canonical symbol, forever.
+            __syncthreads();
+            if ((uint32_t)tid < ocarry) oblk[gpos + tid] = ob[tid];  // unflushed tail (gpos + ocarry == produced)
+            const uint8_t z = L.symtab[0];
+            for (uint32_t i = produced + (uint32_t)tid; i < orig; i += W) oblk[i] = z;
+            break;
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        d_status[b] = status;
+        if (d_errpos) d_errpos[b] = errpos;
+#if DCZ_K4_PROF
+        for (int i = 0; i < 12; i++) atomicAdd(&dfa_prof[i], pacc[i]);
+#endif
+    }
+}
+
+void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                       const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
+                       int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, hipStream_t s) {
+    if (K == 0) return;
+    const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
+    long long* ep = reinterpret_cast<long long*>(d_errpos);
+    static const uint32_t few_below = [] {
+        const char* e = getenv("DCZ_DFA_FEW_BLOCKS_BELOW");  // tuning knob
+        return e ? (uint32_t)atoi(e) : 768u;
+    }();
+    if (K >= few_below)  // 4 workgroups of 4 waves per CU
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
+                           d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls);
+    else  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
+        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size, d_orig_size,
+                           d_len, out_stride, d_out, d_status, ep, ws.cls);
+}
+
+}  // namespace dcz
+
+#if DCZ_K4_PROF
+extern "C" void dcz_debug_dfa_prof(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::dfa_prof), sizeof(dcz::dfa_prof));
+    if (reset) {
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(dcz::dfa_prof), z, sizeof(z));
+    }
+}
+#endif
