@@ -35,6 +35,16 @@ namespace dcz {
 #ifndef DCZ_DFA_OC
 #define DCZ_DFA_OC 16384  // tile bytes per flush: a whole window of text (13.3 KiB on average) in one flush
 #endif
+#ifndef DCZ_DFA_HOIST
+#define DCZ_DFA_HOIST 1  // 1: the 64 nibble offsets of a subsequence are computed once per window and kept in registers
+#endif                   // (1 vector instruction per walk step, ~120 VGPRs); 0: recomputed in every walk (3 per step, ~50 VGPRs)
+#if DCZ_DFA_HOIST
+#define DFA_FRESH(R) do { } while (0)
+#define DFA_FRESH1(r) do { } while (0)
+#else
+#define DFA_FRESH(R) do { } while (0)
+#define DFA_FRESH1(r) asm volatile("" : "+v"(r))  // the nibbles of this dword are extracted here, not before
+#endif
 #ifndef DCZ_DFA_MINWAVES
 #define DCZ_DFA_MINWAVES 4
 #endif
@@ -104,7 +114,7 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 #endif
 
 template <int W, int OC>
-__global__ __launch_bounds__(W, W <= 256 ? DCZ_DFA_MINWAVES : (W <= 512 ? 2 : 1)) void k4_dfa(
+__global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
@@ -293,10 +303,12 @@ __global__ __launch_bounds__(W, W <= 256 ? DCZ_DFA_MINWAVES : (W <= 512 ? 2 : 1)
         while (true) {
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
                 uint32_t e = g << 6, n = 0;
+                DFA_FRESH(R);
                 if (round == 0u) {  // workgroup-uniform
                     auto stepX = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);  // nibble j of the dword, as a byte offset of a u32 entry
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                         const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
                     };
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(W, W <= 256 ? DCZ_DFA_MINWAVES : (W <= 512 ? 2 : 1)
                     auto stepA = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                         const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
                         n += e & 3u;
@@ -378,11 +391,13 @@ __global__ __launch_bounds__(W, W <= 256 ? DCZ_DFA_MINWAVES : (W <= 512 ? 2 : 1)
             const bool mine = nsym > 0u && o >= cbase && o < cend;
             if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
                 uint32_t e = g << 6;
+                DFA_FRESH(R);
                 uint32_t t = mine ? o + tshift : DUMMY;
                 const uint32_t tmask = mine ? 3u : 0u;  // switched-off lanes do not advance: they store to the dummy bytes
                 auto stepB = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
                     constexpr int sh = 26 - 4 * (j & 7);
+                    if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                     const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
                     e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
                     const uint32_t c = e & tmask;

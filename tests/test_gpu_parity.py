@@ -1214,3 +1214,74 @@ def test_north_star_8gib_uniform_random_1mib_chunks(pkg, svc, orc):
     assert (t[:bb].cpu().numpy() == orc.java_random_bytes(42, bb)).all()
     del blk, t
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------
+# The nibble automaton (k4_dfa.hip) on what only it sees differently: incomplete tables (the error state), damage,
+# truncation and requests past the payload in the medium class, in both launch shapes; tables it must hand over (a 1-bit
+# codeword; more than 255 internal nodes) decode through the other kernels with the same results.
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
+@pytest.mark.parametrize("table", ["incomplete", "complete", "one_bit", "deep_chain"])
+def test_medium_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape, table):
+    torch = _torch()
+    rng = np.random.default_rng({"incomplete": 1, "complete": 2, "one_bit": 3, "deep_chain": 4}[table])
+    lens = np.zeros(256, np.int32)
+    if table == "incomplete":
+        syms = rng.choice(256, size=24, replace=False)
+        lens[syms] = rng.integers(3, 9, size=24)  # Kraft sum < 1: damage meets patterns without a codeword
+        while sum(2.0 ** -l for l in lens[lens > 0]) > 1.0:
+            lens[syms[np.argmin(lens[syms])]] += 1
+        probs = None
+    elif table == "complete":
+        data0 = orc.gen_text(7, 0, 200000)
+        _, l0 = orc.encode_block(data0)
+        lens[:] = l0
+        syms = np.nonzero(lens)[0]
+        probs = np.bincount(data0, minlength=256)[syms].astype(float)
+    elif table == "one_bit":
+        syms = np.array([5, 9, 17, 33, 65, 129, 200, 201, 202])
+        lens[syms] = [1, 2, 3, 4, 5, 6, 7, 8, 8]  # complete, with a 1-bit codeword: not the automaton's
+        probs = np.array([2, 2, 3, 6, 10, 16, 20, 20, 21], float)  # skewed to ~5 bits per symbol (medium class)
+    else:  # a few very long codewords: > 255 internal nodes in the code tree
+        syms = rng.choice(256, size=30, replace=False)
+        lens[syms[:12]] = 32
+        lens[syms[12:]] = rng.integers(3, 7, size=18)
+        while sum(2.0 ** -l for l in lens[lens > 0]) > 1.0:
+            lens[syms[12 + int(rng.integers(0, 18))]] += 1
+        probs = np.r_[np.full(12, 1e-4), np.full(18, 1.0)]
+    codes, _ = orc.canonical_codes(lens)
+    p = None if probs is None else probs / probs.sum()
+    K, nsym = (800, 5000) if shape == "many_blocks" else (12, 70000)
+    pays, origs, want = [], [], []
+    for k in range(K):
+        data = rng.choice(syms, size=nsym + k, p=p).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        pay = pay.copy()
+        n = data.size
+        if k % 7 == 3:
+            pay[int(rng.integers(0, pay.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if k % 11 == 5:
+            pay = pay[: pay.size // 2]
+        if k % 13 == 6:
+            n += 300
+        try:
+            want.append((0, 0, orc.decode_block(pay, lens, n)))
+        except orc.DecodeError as e:
+            want.append((pkg.native.DCZ_E_BADSTREAM, e.position, None))
+        pays.append(pay)
+        origs.append(n)
+    sizes = np.array([q.size for q in pays], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
+    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
+    stride = (max(origs) + 15) & ~15
+    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                        torch.tensor(origs, dtype=torch.int32, device="cuda"),
+                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
+    torch.cuda.synchronize()
+    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
+    for k, (wst, wpos, wdata) in enumerate(want):
+        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
+        if wst:
+            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
+        else:
+            assert (out[k * stride:k * stride + origs[k]] == wdata).all(), "block %d decodes differently" % k
