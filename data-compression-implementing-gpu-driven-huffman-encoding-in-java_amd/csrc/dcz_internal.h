@@ -85,7 +85,7 @@ void launch_decode_regwin(const uint8_t* d_comp, const uint64_t* d_comp_off, con
 // k4_dfa.hip: nibble automaton for the medium class (one workgroup per block)
 void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                        const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                       int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, hipStream_t s);
+                       int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, uint32_t split_grid, hipStream_t s);
 
 // K5: SHA-256 of every block -> digests[K][32].
 void launch_sha256(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t K, uint8_t* d_digests, hipStream_t s);

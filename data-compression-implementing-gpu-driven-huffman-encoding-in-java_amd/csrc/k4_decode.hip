@@ -464,7 +464,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
 #if DCZ_K4_MEDIUM_DFA
-        if constexpr (CMASK == 2 && MODE == 0) {
+        if constexpr (CMASK == 2 && (MODE == 0 || MODE == 3)) {
             // blocks the nibble automaton takes (k4_dfa.hip applies the same test to the same table): no 1-bit codeword
             // and at most 255 internal nodes in the code tree; this kernel keeps the rest of the medium class
             uint32_t ni = 0, states = 0;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
                 ni = (L.cnt[l + 1] + ni + 1u) / 2u;
                 states += ni;
             }
-            L.dfa_takes = (L.cnt[1] == 0u && states <= 255u && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
+            L.dfa_takes = (L.cnt[1] == 0u && states <= (MODE == 3 ? 253u : 255u) && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
         }
 #endif
         L.nomiss = (mx >= 1u && mx <= (uint32_t)TB && kraft == (1ull << 32)) ? 1u : 0u;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         return;
     }
 #if DCZ_K4_MEDIUM_DFA
-    if constexpr (CMASK == 2 && MODE == 0) {
+    if constexpr (CMASK == 2 && (MODE == 0 || MODE == 3)) {
         if (L.dfa_takes) return;  // workgroup-uniform
     }
 #endif
@@ -1274,6 +1274,10 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
             const uint32_t grid = K * sd.rmax;
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 3);
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 3);
+#if DCZ_K4_MEDIUM_DFA
+            launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws,
+                              grid, s);
+#endif
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 3);
         }
     }
@@ -1300,7 +1304,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 0);
 #endif
 #if DCZ_K4_MEDIUM_DFA
-        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, s);
+        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, 0, s);
 #endif
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT
@@ -1322,7 +1326,7 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 0);
 #endif
 #if DCZ_K4_MEDIUM_DFA
-        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, s);
+        launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, 0, s);
 #endif
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, 0, true, 1, DCZ_K4_TBS, 0);
 #if DCZ_K4_EXACT

@@ -113,28 +113,39 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 #define DFA_T(i) do { } while (0)
 #endif
 
-template <int W, int OC>
+// SPLIT: one workgroup per REGION of a block that k4_split.hip has cut up (sdp: the region table); otherwise per block.
+template <int W, int OC, bool SPLIT>
 __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
-    uint8_t* __restrict__ d_cls) {
+    uint8_t* __restrict__ d_cls, const SplitDesc* __restrict__ sdp) {
     using LdsT = DfaLds<W, OC>;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x, reg = 0;
     const int tid = (int)threadIdx.x;
 #if DCZ_K4_PROF
     unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long plast = clock64();
 #endif
-    if (d_cls[b] != 0) return;  // fixed-length, exact-entry, split or rejected block (workgroup-uniform)
-    const uint32_t orig = d_orig_size[b];
+    if constexpr (SPLIT) {
+        const uint32_t rmax = sdp->rmax;
+        b = blockIdx.x / rmax;
+        reg = blockIdx.x - b * rmax;
+        if (d_cls[b] != 2 || reg >= sdp->nreg[b]) return;  // workgroup-uniform
+    } else {
+        if (d_cls[b] != 0) return;  // fixed-length, exact-entry, split or rejected block (workgroup-uniform)
+    }
+    const uint32_t orig_blk = d_orig_size[b];
     const unsigned long long coff = d_comp_off[b];
     const uint32_t csize = d_comp_size[b];
+    // symbols this workgroup produces: the whole chunk, or what k4_split_scan gave its region
+    const uint32_t orig = SPLIT ? sdp->count[(uint64_t)b * sdp->rmax + reg] : orig_blk;
+    if (SPLIT && orig == 0u) return;
     {
-        const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig * 13ull;
-        const bool medium = (unsigned long long)orig * (unsigned long long)DCZ_K4_CLS2_A <=
+        const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig_blk * 13ull;
+        const bool medium = (unsigned long long)orig_blk * (unsigned long long)DCZ_K4_CLS2_A <=
                             (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B;
         if (long_codes || !medium) return;  // workgroup-uniform; other launches own those blocks
     }
@@ -189,7 +200,8 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         return;
     }
     // tables this automaton does not take (k4_decode.hip's medium-class kernel applies the same test and decodes them)
-    if (L.cnt[1] != 0u || L.nstates > 255u || L.maxlen == 0u) return;
+    // (a region adds up to two rows for its entry, see below)
+    if (L.cnt[1] != 0u || L.nstates > (SPLIT ? 253u : 255u) || L.maxlen == 0u) return;
     for (int sy = tid; sy < 256; sy += W) {
         const uint32_t l = L.len8[sy];
         if (l > 0) {
@@ -234,17 +246,52 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     }
     const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.T[0]));
 
-    uint8_t* const oblk = out + (uint64_t)b * out_stride;
-    const bool out_aligned = (((uintptr_t)oblk) & 15u) == 0u;
+    // output of this workgroup: the chunk's slot, or the region's offset inside it.  A region starts at any byte: the
+    // tile is laid over the 16-byte unit that holds its first byte, whose first hskip bytes belong to the region before.
+    uint8_t* const oblk = out + (uint64_t)b * out_stride + (SPLIT ? sdp->off[(uint64_t)b * sdp->rmax + reg] : 0u);
+    uint32_t hskip = SPLIT ? (uint32_t)(((uintptr_t)oblk) & 15u) : 0u;
+    uint8_t* const obase = oblk - hskip;
+    const bool out_aligned = (((uintptr_t)obase) & 15u) == 0u;
     const uintptr_t pay = (uintptr_t)comp + (uintptr_t)coff;
     const uint32_t skew = (uint32_t)(pay & 15u);
     const uint8_t* const vbase = reinterpret_cast<const uint8_t*>(pay - skew);
     const unsigned long long vlo = skew, vhi = (unsigned long long)skew + csize;
-    const uint32_t sq = skew >> 2, sr = skew & 3u;
 
-    uint32_t produced = 0, gpos = 0, ocarry = 0;
+    uint32_t produced = 0, gpos = 0, ocarry = hskip;
     uint32_t entry0 = 0;  // state at the first nibble of the window (the block starts at the root)
     unsigned long long wbyte = 0;  // payload byte of the window's first subsequence
+    if constexpr (SPLIT) {
+        // The region's proven entry is a BIT (first codeword boundary at or past the region start).  The walk starts at
+        // the byte that holds it; two extra table rows bring lane 0 from there to the automaton proper:
+        //   row ENT: the nibble that holds the entry bit -- only its bits from the entry on are walked, from the root;
+        //   row SKIP: a nibble that lies wholly before the entry bit: any input leads to ENT (or the root), no symbol.
+        const unsigned long long ebit = 8ull * reg * sdp->region_bytes + sdp->entry[(uint64_t)b * sdp->rmax + reg] - 8ull * skew;
+        wbyte = ebit >> 3;
+        const uint32_t xb = (uint32_t)(ebit & 7ull), kskip = xb >> 2, rb = xb & 3u;
+        const uint32_t ENT = L.nstates, SKIP = L.nstates + 1u;
+        __syncthreads();  // (T's regular rows are written)
+        if (tid < 16) {
+            const uint32_t nib = (uint32_t)tid;
+            uint32_t l = 0, p = 0, c = 0, syms = 0;
+            bool err = false;
+            for (int i = 3 - (int)rb; i >= 0 && !err; i--) {
+                p = 2u * p + ((nib >> i) & 1u);
+                l++;
+                const uint32_t rel = p - L.first[l];
+                if (rel < L.cnt[l]) {
+                    syms |= (uint32_t)L.symtab[L.offs[l] + rel] << (8 * c);
+                    c++;
+                    l = 0;
+                    p = 0;
+                } else if (rel - L.cnt[l] >= L.nint[l]) {
+                    err = true;
+                }
+            }
+            L.T[ENT * 16u + nib] = err ? ((DFA_ERR << 6) | 4u) : (((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (syms << 16));
+            L.T[SKIP * 16u + nib] = (rb ? ENT : 0u) << 6;
+        }
+        entry0 = kskip ? SKIP : (rb ? ENT : 0u);
+    }
     int status = DCZ_OK;
     long long errpos = 0;
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.tile);
@@ -257,7 +304,11 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
 #pragma unroll
         for (int c = 0; c < 3; c++) pre[c] = load_chunk16(vbase, v0 + 16ull * c, vlo, vhi);
     };
-    if (orig > 0) prefetch(0);
+    // byte offset of a lane's first payload byte inside its first aligned chunk: the same for every lane and window
+    // (lanes are 32 bytes apart, windows W * 32)
+    const uint32_t sk2 = (skew + (uint32_t)(wbyte & 15ull)) & 15u;
+    const uint32_t sq = sk2 >> 2, sr = sk2 & 3u;
+    if (orig > 0) prefetch(wbyte);
     __syncthreads();  // T complete
     DFA_T(0);
 
@@ -347,9 +398,11 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             g = ng;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
             round++;
-            if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
-                if (tid == 0) d_cls[b] = 1;                // the exact-entry launch (k4_decode.hip, MODE 1) decodes it
-                return;
+            if constexpr (!SPLIT) {  // (a proven region simply keeps iterating: at most W rounds)
+                if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
+                    if (tid == 0) d_cls[b] = 1;                // the exact-entry launch (k4_decode.hip, MODE 1) decodes it
+                    return;
+                }
             }
         }
 
@@ -420,15 +473,15 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             const uint32_t total = ocarry + cc;
             const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
             const uint32_t full = last ? total : (total & ~15u);
-            uint8_t* const dst = oblk + gpos;
+            uint8_t* const dst = obase + gpos;
             const uint32_t nunits = (full + 15u) >> 4;
             for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
                 const uint32_t lo = u << 4;
                 const uint32_t* src = &L.tile[lo >> 2];
-                if (out_aligned && lo + 16u <= full) {
+                if (out_aligned && lo + 16u <= full && lo >= hskip) {
                     *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
                 } else {
-                    for (uint32_t i = lo; i < lo + 16u && i < full; i++) dst[i] = ob[i];
+                    for (uint32_t i = lo > hskip ? lo : hskip; i < lo + 16u && i < full; i++) dst[i] = ob[i];
                 }
             }
             const uint32_t tail = total - full;  // < 16
@@ -438,6 +491,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             if ((uint32_t)tid < tail) ob[tid] = tv;
             gpos += full;
             ocarry = tail;
+            if (full > 0u) hskip = 0;  // (the unit shared with the region before has been written)
             cbase = cend;
             DFA_T(7);
         }
@@ -448,7 +502,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             // The payload is used up but the chunk wants more symbols: the reference keeps reading zero bits
             // (TableBasedHuffmanDecoder.java:204-208), i.e. the all-zero codeword = first canonical symbol, forever.
             __syncthreads();
-            if ((uint32_t)tid < ocarry) oblk[gpos + tid] = ob[tid];  // unflushed tail (gpos + ocarry == produced)
+            if ((uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[tid];  // unflushed tail
             const uint8_t z = L.symtab[0];
             for (uint32_t i = produced + (uint32_t)tid; i < orig; i += W) oblk[i] = z;
             break;
@@ -456,31 +510,37 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         __syncthreads();
     }
 
-    if (tid == 0) {
+    if (tid == 0 && (!SPLIT || status != DCZ_OK)) {  // (a split block got its status from k4_split_scan)
         d_status[b] = status;
-        if (d_errpos) d_errpos[b] = errpos;
+        if (d_errpos) d_errpos[b] = errpos + (SPLIT ? (long long)sdp->off[(uint64_t)b * sdp->rmax + reg] : 0ll);
+    }
 #if DCZ_K4_PROF
+    if (tid == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&dfa_prof[i], pacc[i]);
 #endif
-    }
 }
 
 void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                        const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                       int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, hipStream_t s) {
+                       int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, uint32_t split_grid, hipStream_t s) {
     if (K == 0) return;
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
+    if (split_grid) {  // one workgroup per (block, region)
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, true>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, ws.sdesc);
+        return;
+    }
     static const uint32_t few_below = [] {
         const char* e = getenv("DCZ_DFA_FEW_BLOCKS_BELOW");  // tuning knob
         return e ? (uint32_t)atoi(e) : 768u;
     }();
     if (K >= few_below)  // 4 workgroups of 4 waves per CU
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
-                           d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls);
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
+                           d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
     else  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
-        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size, d_orig_size,
-                           d_len, out_stride, d_out, d_status, ep, ws.cls);
+        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+                           d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 }
 
 }  // namespace dcz
