@@ -1,14 +1,23 @@
 #!/bin/bash
-# Regenerates everything under profiles/ for one version tag (run on the GPU box from the repo root).
+# Regenerates the round's evidence under gpurun_out/ for one tag (run on the GPU box from the repo root); copy what is to
+# be judged into profiles/ afterwards (tools/collect_profiles.sh <tag> <round>).
+#   per workload: rocprofv3 kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc passes), SQ counters
+#   bench lines for every workload (hipEvent kernel times, roofline, cpu_baseline on the default one), 2-rank gloo rehearsal
 set -o pipefail
 V=$1; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$V -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-sample-mib 0 > $R/gpurun_out/stats_$V.json 2> $R/gpurun_out/stats_$V.err || echo "stats failed"
 cd $R
-cp $(ls gpurun_out/stats_$V/*/*_kernel_stats.csv | head -1) gpurun_out/kernel_stats_$V.csv || echo "no stats csv"
-bash tools/traffic.sh $V > gpurun_out/traffic_$V.txt 2>&1 && python3 tools/mk_traffic.py $V random8g 8589934592 1048576 "build $V" > gpurun_out/traffic_json_$V.txt
-bash tools/pmc.sh $V > gpurun_out/pmc_sq_$V.txt 2>&1
+# HBM traffic of the default workload first: bench.py quotes it as roofline.traffic when the shapes match
+export TMPDIR=/tmp
+( cd /tmp; for P in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/trf_${V}_$P -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-mib 0 --no-verify > /dev/null 2> $R/gpurun_out/trf_${V}_$P.err || echo "pass $P failed"
+  done )
+python3 tools/mk_traffic.py $V random8g 8589934592 1048576 "build $V" > gpurun_out/traffic_json_$V.txt 2>&1 || echo "mk_traffic failed"
+rm -rf gpurun_out/trf_${V}_FETCH_SIZE gpurun_out/trf_${V}_WRITE_SIZE
+bash tools/profile_workload.sh ${V}_random8g
+bash tools/profile_workload.sh ${V}_text8g --workload text8g
+bash tools/profile_workload.sh ${V}_lowentropy --workload lowentropy
+bash tools/profile_workload.sh ${V}_text32m --workload text_32m
 timeout -k 10 600 python bench.py > gpurun_out/bench_random8g_$V.json 2> gpurun_out/bench_random8g_$V.err || echo "bench default failed"
-for w in random256m text lowentropy; do timeout -k 10 300 python bench.py --workload $w --cpu-sample-mib 0 > gpurun_out/bench_${w}_$V.json 2>/dev/null || echo "bench $w failed"; done
-timeout -k 10 300 python bench.py --workload text --bytes-per-gpu 8589934592 --cpu-sample-mib 0 > gpurun_out/bench_text8g_$V.json 2>/dev/null || echo "bench text8g failed"
+for w in random256m text text8g lowentropy text_32m; do timeout -k 10 300 python bench.py --workload $w --cpu-sample-mib 0 > gpurun_out/bench_${w}_$V.json 2>/dev/null || echo "bench $w failed"; done
 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --backend gloo --single-device --bytes-per-gpu 2147483648 --cpu-sample-mib 0 > gpurun_out/bench_2rank_$V.json 2> gpurun_out/bench_2rank_$V.err || echo "2rank failed"
-python tools/summ.py gpurun_out/bench_random8g_$V.json gpurun_out/bench_random256m_$V.json gpurun_out/bench_text_$V.json gpurun_out/bench_text8g_$V.json gpurun_out/bench_lowentropy_$V.json
+python tools/summ.py gpurun_out/bench_random8g_$V.json gpurun_out/bench_random256m_$V.json gpurun_out/bench_text_$V.json gpurun_out/bench_text8g_$V.json gpurun_out/bench_lowentropy_$V.json gpurun_out/bench_text_32m_$V.json
