@@ -222,9 +222,11 @@ def main():
         # K5 beside the codec: per-chunk SHA-256 of the resident input, one lane per chunk.
         # Not part of `value` (8(d) excludes CHECKSUM_* stages).
         svc.sha256_device(t_in, chunk)
+        torch.cuda.synchronize(dev)
         ts = time.perf_counter()
         for _ in range(2):
             svc.sha256_device(t_in, chunk)
+        torch.cuda.synchronize(dev)
         line["sha256_per_chunk"] = {"gbps": round(2 * per_gpu / (time.perf_counter() - ts) / 1e9, 2), "chunks": k_local,
                                     "note": "one lane per chunk; throughput scales with the number of chunks"}
         if world == 1 and args.cpu_sample_mib != 0:
