@@ -45,6 +45,12 @@ namespace dcz {
 #define DFA_FRESH(R) do { } while (0)
 #define DFA_FRESH1(r) asm volatile("" : "+v"(r))  // the nibbles of this dword are extracted here, not before
 #endif
+#ifndef DCZ_DFA_X_FROM
+#define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
+#endif
+#ifndef DCZ_DFA_ABL
+#define DCZ_DFA_ABL 0  // timing ablations (WRONG output): 1 = phase B stores all go to the dummy bytes, 2 = no phase B stores,
+#endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
 #ifndef DCZ_DFA_MINWAVES
 #define DCZ_DFA_MINWAVES 4
 #endif
@@ -64,7 +70,7 @@ template <int W, int OC>
 struct DfaLds {
     static constexpr int CAP = OC + 512;  // tile capacity (the last lane of a flush may run 300 bytes past its end)
     __attribute__((aligned(16))) uint32_t T[256 * 16];          // [state][nibble]
-    __attribute__((aligned(16))) uint32_t tile[CAP / 4 + 160];  // + slack for the dummy bytes of switched-off lanes
+    __attribute__((aligned(16))) uint32_t tile[CAP / 4 + 160];  // (+ slack)
     uint8_t exits[W];
     uint8_t node_l[256];   // depth of internal node `id`
     uint32_t node_p[256];  // its prefix (the l bits that lead to it)
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     using LdsT = DfaLds<W, OC>;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     uint32_t b = blockIdx.x, reg = 0;
     const int tid = (int)threadIdx.x;
 #if DCZ_K4_PROF
@@ -240,11 +247,12 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     err = true;  // no codeword has this prefix (incomplete code)
                 }
             }
-            if (!err) e = ((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (syms << 16);
+            if (!err) e = ((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16);
         }
         L.T[idx] = e;
     }
     const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.T[0]));
+    const uint32_t tile_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.tile[0]));
 
     // output of this workgroup: the chunk's slot, or the region's offset inside it.  A region starts at any byte: the
     // tile is laid over the 16-byte unit that holds its first byte, whose first hskip bytes belong to the region before.
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     err = true;
                 }
             }
-            L.T[ENT * 16u + nib] = err ? ((DFA_ERR << 6) | 4u) : (((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (syms << 16));
+            L.T[ENT * 16u + nib] =
+                err ? ((DFA_ERR << 6) | 4u) : (((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16));
             L.T[SKIP * 16u + nib] = (rb ? ENT : 0u) << 6;
         }
         entry0 = kskip ? SKIP : (rb ? ENT : 0u);
@@ -295,7 +304,6 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     int status = DCZ_OK;
     long long errpos = 0;
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.tile);
-    constexpr uint32_t DUMMY = (uint32_t)LdsT::CAP + 320u;  // tile bytes nobody flushes
 
     // this lane's 32 payload bytes of the window at `wb`: three aligned chunks, shifted by the payload's skew
     uint4 pre[3];
@@ -309,6 +317,8 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint32_t sk2 = (skew + (uint32_t)(wbyte & 15ull)) & 15u;
     const uint32_t sq = sk2 >> 2, sr = sk2 & 3u;
     if (orig > 0) prefetch(wbyte);
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)(sizeof(L.tile) / 16u); i += W)  // phase B ORs into the tile
+        reinterpret_cast<uint4*>(L.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();  // T complete
     DFA_T(0);
 
@@ -350,12 +360,13 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         uint32_t g = (tid == 0) ? entry0 : 0u;  // entry state
         uint32_t x = 0, nsym = 0;
         bool need = !beyond;
-        uint32_t round = 0;
+        uint32_t round = (DCZ_DFA_ABL & 4) ? 1u : 0u;
         while (true) {
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
                 uint32_t e = g << 6, n = 0;
                 DFA_FRESH(R);
                 if (round == 0u) {  // workgroup-uniform
+                    if (DCZ_DFA_X_FROM > 0) e = 0;  // (mid-subsequence every lane guesses "codeword boundary")
                     auto stepX = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);  // nibble j of the dword, as a byte offset of a u32 entry
@@ -363,9 +374,12 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                         const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
                     };
+                    // The guess only has to be right often: the walk covers the subsequence's last 64 - DCZ_DFA_X_FROM
+                    // nibbles (text synchronises within 5 nibbles on average, 0.03 % of the subsequences need more
+                    // than 48); a wrong exit is found and repaired by the rounds that follow.  Text 8 GiB: 8.37 ms from nibble 0, 8.02 from 16 or 24, 8.34 from 32 (more repair rounds), 8.98 from 48.
                     [&]<int... Js>(std::integer_sequence<int, Js...>) {
-                        (stepX(std::integral_constant<int, Js>{}), ...);
-                    }(std::make_integer_sequence<int, 64>{});
+                        (stepX(std::integral_constant<int, DCZ_DFA_X_FROM + Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64 - DCZ_DFA_X_FROM>{});
                 } else {
                     auto stepA = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             __syncthreads();
             DFA_T(3);
             if (round > 1u && L.flag[round % 3u] == 0u) break;
+            if (DCZ_DFA_ABL & 16) break;
             const uint32_t ng = (tid == 0) ? entry0 : (uint32_t)L.exits[tid - 1];
             need = ((ng != g) || round == 0u) && !beyond;  // after the exit-only round everybody walks once more
             g = ng;
@@ -442,28 +457,54 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             // a lane takes part in this flush when its first symbol lies inside it (flushes end on subsequence
             // boundaries; at the end of the block the last lane may run past `lim` into the tile's slack)
             const bool mine = nsym > 0u && o >= cbase && o < cend;
-            if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+            // Symbols are collected in a 64-bit register and leave as whole dwords: a lane stores the tile dword that
+            // holds its k-th .. (k+3)-th byte when it has them (checked every second step: at most 3 + 4 bytes wait).
+            // The dword a lane shares with its left neighbour gets the lane's plain store with the neighbour's bytes as
+            // zeros; what is left in the register after the walk (the lane's bytes of the dword it shares with its right
+            // neighbour) is ORed in after a barrier, when all plain stores are done.  Dwords that only receive ORs were
+            // zeroed by the flush that read them last.
+            uint32_t ab = 0, k8 = 0, alo = 0;  // ab: LDS byte address of the dword being collected
+            if (!(DCZ_DFA_ABL & 8) && __builtin_amdgcn_ballot_w64(mine) != 0ull) {
                 uint32_t e = g << 6;
                 DFA_FRESH(R);
-                uint32_t t = mine ? o + tshift : DUMMY;
-                const uint32_t tmask = mine ? 3u : 0u;  // switched-off lanes do not advance: they store to the dummy bytes
-                auto stepB = [&](auto jc) __attribute__((always_inline)) {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int sh = 26 - 4 * (j & 7);
+                const uint32_t p0 = mine ? o + tshift : 0u;
+                ab = tile_addr + (p0 & ~3u);
+                k8 = (p0 & 3u) << 3;
+                uint32_t ahi = 0;
+                // (the first lane of a flush continues the bytes the flush before left in the tile)
+                if (mine && o == cbase) alo = *(lds_u32*)(uintptr_t)ab & ((1u << k8) - 1u);
+                const uint32_t tmask = mine ? 0x18u : 0u;  // switched-off lanes collect nothing
+                auto stepB = [&](auto jc) __attribute__((always_inline)) {  // two nibbles: up to four symbols
+                    constexpr int j = 2 * decltype(jc)::value;
+                    constexpr int sh0 = 26 - 4 * (j & 7), sh1 = 26 - 4 * ((j + 1) & 7);
                     if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                    const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
-                    const uint32_t c = e & tmask;
-                    // (a step that completes nothing must not store: after the lane's last symbol, t is the next
-                    // lane's first byte)
-                    ob[c >= 1u ? t : DUMMY] = (uint8_t)(e >> 16);
-                    (ob + 1)[c >= 2u ? t : DUMMY + 4u] = (uint8_t)(e >> 24);  // the second symbol, if there is one
-                    t += c;
+                    const uint32_t nib0 = (R[j >> 3] >> sh0) & 0x3Cu;
+                    const uint32_t nib1 = sh1 >= 0 ? ((R[j >> 3] >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                    const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib0));
+                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & 0xFFC0u) | nib1));
+                    const uint32_t c0 = e0 & tmask;  // 8 * symbols of the first nibble (bytes past the count are zero)
+                    const uint32_t w = ((e >> 16) << c0) | (e0 >> 16);
+                    const unsigned long long v = (unsigned long long)w << k8;
+                    alo |= (uint32_t)v;
+                    ahi |= (uint32_t)(v >> 32);
+                    k8 += c0 + (e & tmask);
+                    if (k8 >= 32u) {
+#if !(DCZ_DFA_ABL & 2)
+                        *(lds_u32*)(uintptr_t)ab = alo;
+#endif
+                        alo = ahi;
+                        ahi = 0;
+                        k8 -= 32u;
+                        ab += 4u;
+                    }
                 };
                 [&]<int... Js>(std::integer_sequence<int, Js...>) {
                     (stepB(std::integral_constant<int, Js>{}), ...);
-                }(std::make_integer_sequence<int, 64>{});
+                }(std::make_integer_sequence<int, 32>{});
             }
+            __syncthreads();
+            if (k8 != 0u)
+                __hip_atomic_fetch_or((lds_u32*)(uintptr_t)ab, alo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             DFA_T(5);
 #if DCZ_K4_PROF
             pacc[10]++;
@@ -483,17 +524,22 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                 } else {
                     for (uint32_t i = lo > hskip ? lo : hskip; i < lo + 16u && i < full; i++) dst[i] = ob[i];
                 }
+                *reinterpret_cast<uint4*>(&L.tile[lo >> 2]) = make_uint4(0u, 0u, 0u, 0u);
             }
             const uint32_t tail = total - full;  // < 16
             uint8_t tv = 0;
             if ((uint32_t)tid < tail) tv = ob[full + tid];
             __syncthreads();
-            if ((uint32_t)tid < tail) ob[tid] = tv;
+            if (full > 0u) {  // the ragged tail moves to the front of the (zeroed) tile
+                if (tid < 4) L.tile[(full >> 2) + (uint32_t)tid] = 0u;
+                if ((uint32_t)tid < tail) ob[tid] = tv;
+            }
             gpos += full;
             ocarry = tail;
             if (full > 0u) hskip = 0;  // (the unit shared with the region before has been written)
             cbase = cend;
             DFA_T(7);
+            if (cbase < lim) __syncthreads();  // (the next flush reads the bytes carried over)
         }
         produced += lim;
         entry0 = next_entry;
