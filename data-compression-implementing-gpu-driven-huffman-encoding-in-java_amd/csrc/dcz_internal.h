@@ -37,6 +37,10 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
 
 // K4: decode.  Region table of the split decoder (k4_split.hip): a block cut into regions of region_bytes of payload,
 // one workgroup per region; the arrays are [block][rmax].
+#ifndef DCZ_K4_SPARSE_DFA
+#define DCZ_K4_SPARSE_DFA 1  // sparse short-code blocks (one 1-bit symbol, < 1.3 bits/symbol): k4_dfa's SPARSE instantiation
+#endif
+
 struct SplitDesc {
     uint32_t* entry;   // bits from the region's first payload bit (virtual) to its first codeword
     uint32_t* count;   // symbols the region produces

@@ -475,6 +475,19 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
             L.dfa_takes = (L.cnt[1] == 0u && states <= (MODE == 3 ? 253u : 255u) && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
         }
 #endif
+#if DCZ_K4_SPARSE_DFA
+        if constexpr (CMASK == 1 && MODE == 0) {
+            // sparse blocks the automaton takes (k4_dfa.hip, SPARSE instantiation, same test on the same numbers): one
+            // 1-bit codeword, < 1.3 bits per symbol, at most 255 internal nodes
+            uint32_t ni = 0, states = 0;
+            for (int l = 31; l >= 0; l--) {
+                ni = (L.cnt[l + 1] + ni + 1u) / 2u;
+                states += ni;
+            }
+            L.dfa_takes = (L.cnt[1] == 1u && states <= 255u && mx >= 2u && kraft <= (1ull << 32) &&
+                           (unsigned long long)csize * 80ull < (unsigned long long)orig_blk * 13ull) ? 1u : 0u;
+        }
+#endif
         L.nomiss = (mx >= 1u && mx <= (uint32_t)TB && kraft == (1ull << 32)) ? 1u : 0u;
         if (kraft > (1ull << 32)) L.bad_table = 1;  // not a prefix code
         // every codeword has the same length and that length divides the subsequence: always in phase
@@ -491,6 +504,11 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
     }
 #if DCZ_K4_MEDIUM_DFA
     if constexpr (CMASK == 2 && (MODE == 0 || MODE == 3)) {
+        if (L.dfa_takes) return;  // workgroup-uniform
+    }
+#endif
+#if DCZ_K4_SPARSE_DFA
+    if constexpr (CMASK == 1 && MODE == 0) {
         if (L.dfa_takes) return;  // workgroup-uniform
     }
 #endif

@@ -120,7 +120,18 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 #endif
 
 // SPLIT: one workgroup per REGION of a block that k4_split.hip has cut up (sdp: the region table); otherwise per block.
-template <int W, int OC, bool SPLIT>
+//
+// SPARSE: the automaton for blocks of the SHORT-code class that are almost entirely one symbol z with a 1-bit codeword
+// (< 1.3 bits per symbol; e.g. zero pages with 1 % noise: 237 symbols per 32-byte subsequence).  A nibble then completes
+// up to FOUR symbols, of which at most two are not z (a codeword other than z has >= 2 bits; two of them fit a nibble
+// only as [rest of a codeword, 1 bit][2 bits][z] or [..][z][2 bits] or [2 bits][2 bits] or [.., 2][2]: the first symbol
+// of the nibble is then one of the two):
+//   T[state][nibble] = count (0..4) | others (0..2) << 3 | next << 6 | pos << 14 | sym0 << 16 | sym1 << 24
+//   (one other symbol: sym0 at index pos of the nibble's symbols; two: sym0 at index 0 and sym1 at index pos).
+// Walks are the same (entry/exit states, fixed point, scan of the counts); the output pass has no tile: the window's
+// output range is filled with z by 16-byte stores and the walk stores the other symbols as single bytes straight to
+// global memory (the scheme of k4_decode.hip's sparse path, whose table walk this replaces: 4.25 -> see DESIGN.md).
+template <int W, int OC, bool SPLIT, bool SPARSE>
 __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
@@ -154,7 +165,13 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig_blk * 13ull;
         const bool medium = (unsigned long long)orig_blk * (unsigned long long)DCZ_K4_CLS2_A <=
                             (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B;
-        if (long_codes || !medium) return;  // workgroup-uniform; other launches own those blocks
+        if constexpr (SPARSE) {
+            static_assert(!SPLIT, "regions of sparse blocks are decoded by k4_decode.hip");
+            const bool sparse = (unsigned long long)csize * 80ull < (unsigned long long)orig_blk * 13ull;
+            if (long_codes || medium || !sparse) return;
+        } else {
+            if (long_codes || !medium) return;  // workgroup-uniform; other launches own those blocks
+        }
     }
 
     // ---- per-block tables (rebuildCodes: CpuCompressionService.java:582-586 -> CanonicalHuffman.java:99-132) ----
@@ -208,7 +225,11 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     }
     // tables this automaton does not take (k4_decode.hip's medium-class kernel applies the same test and decodes them)
     // (a region adds up to two rows for its entry, see below)
-    if (L.cnt[1] != 0u || L.nstates > (SPLIT ? 253u : 255u) || L.maxlen == 0u) return;
+    if constexpr (SPARSE) {  // (k4_decode.hip's short-code kernel applies the same test and leaves the block alone)
+        if (L.cnt[1] != 1u || L.nstates > 255u || L.maxlen < 2u) return;
+    } else {
+        if (L.cnt[1] != 0u || L.nstates > (SPLIT ? 253u : 255u) || L.maxlen == 0u) return;
+    }
     for (int sy = tid; sy < 256; sy += W) {
         const uint32_t l = L.len8[sy];
         if (l > 0) {
@@ -226,9 +247,11 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     __syncthreads();
     for (uint32_t idx = (uint32_t)tid; idx < 256u * 16u; idx += W) {
         const uint32_t st = idx >> 4, nib = idx & 15u;
-        uint32_t e = (DFA_ERR << 6) | 4u;  // unused rows and the error state: stay in the error state
+        uint32_t e = DFA_ERR << 6;  // unused rows and the error state: stay in the error state
         if (st < L.nstates) {
             uint32_t l = L.node_l[st], p = L.node_p[st], c = 0, syms = 0;
+            uint32_t nz = 0, pos = 0;  // SPARSE: symbols other than z and the index of the last one
+            const uint32_t z = L.symtab[0];
             bool err = false;
             for (int i = 3; i >= 0 && !err; i--) {
                 p = 2u * p + ((nib >> i) & 1u);
@@ -239,7 +262,16 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                 }
                 const uint32_t rel = p - L.first[l];
                 if (rel < L.cnt[l]) {  // a leaf: the codeword is complete
-                    syms |= (uint32_t)L.symtab[L.offs[l] + rel] << (8 * c);
+                    const uint32_t sy = L.symtab[L.offs[l] + rel];
+                    if constexpr (SPARSE) {
+                        if (sy != z) {
+                            syms |= sy << (8 * nz);
+                            pos = c;
+                            nz++;
+                        }
+                    } else {
+                        syms |= sy << (8 * c);
+                    }
                     c++;
                     l = 0;
                     p = 0;
@@ -247,7 +279,11 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     err = true;  // no codeword has this prefix (incomplete code)
                 }
             }
-            if (!err) e = ((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16);
+            // (a nibble that leaves the code tree still counts the symbols it completed before: the reference's error
+            // position is the number of symbols decoded so far)
+            const uint32_t next = err ? DFA_ERR : L.base[l] + (p - L.first[l] - L.cnt[l]);
+            if constexpr (SPARSE) e = c | (nz << 3) | (next << 6) | (pos << 14) | (syms << 16);
+            else e = (next << 6) | c | (c << 3) | (syms << 16);
         }
         L.T[idx] = e;
     }
@@ -295,14 +331,14 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     err = true;
                 }
             }
-            L.T[ENT * 16u + nib] =
-                err ? ((DFA_ERR << 6) | 4u) : (((L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16));
+            L.T[ENT * 16u + nib] = ((err ? DFA_ERR : L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16);
             L.T[SKIP * 16u + nib] = (rb ? ENT : 0u) << 6;
         }
         entry0 = kskip ? SKIP : (rb ? ENT : 0u);
     }
     int status = DCZ_OK;
     long long errpos = 0;
+    constexpr uint32_t AMASK = SPARSE ? 0x3FC0u : 0xFFC0u;  // state field of an entry, as the byte offset of its row
     uint8_t* const ob = reinterpret_cast<uint8_t*>(L.tile);
 
     // this lane's 32 payload bytes of the window at `wb`: three aligned chunks, shifted by the payload's skew
@@ -372,7 +408,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                         constexpr int sh = 26 - 4 * (j & 7);  // nibble j of the dword, as a byte offset of a u32 entry
                         if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                         const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                     };
                     // The guess only has to be right often: the walk covers the subsequence's last 64 - DCZ_DFA_X_FROM
                     // nibbles (text synchronises within 5 nibbles on average, 0.03 % of the subsequences need more
@@ -386,8 +422,8 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                         constexpr int sh = 26 - 4 * (j & 7);
                         if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                         const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib4));
-                        n += e & 3u;
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
+                        n += e & (SPARSE ? 7u : 3u);
                     };
                     [&]<int... Js>(std::integer_sequence<int, Js...>) {
                         (stepA(std::integral_constant<int, Js>{}), ...);
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             g = ng;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
             round++;
-            if constexpr (!SPLIT) {  // (a proven region simply keeps iterating: at most W rounds)
+            if constexpr (!SPLIT && !SPARSE) {  // (a proven region and a sparse block simply keep iterating: at most W rounds)
                 if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
                     if (tid == 0) d_cls[b] = 1;                // the exact-entry launch (k4_decode.hip, MODE 1) decodes it
                     return;
@@ -439,6 +475,56 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         const bool more = produced + lim < orig;
         DFA_T(4);
 
+        if constexpr (SPARSE) {
+            // ---- phase B, sparse: fill the window's output with z, then the same walk stores the other symbols ----
+            uint8_t* const dst = oblk + produced;  // lim bytes
+            {
+                const uint32_t z = L.symtab[0];
+                uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+                if (head > lim) head = lim;
+                if ((uint32_t)tid < head) dst[tid] = (uint8_t)z;
+                const uint32_t body = (lim - head) >> 4;
+                const uint32_t z4 = z * 0x01010101u;
+                uint4* const d4 = reinterpret_cast<uint4*>(dst + head);
+                for (uint32_t u = (uint32_t)tid; u < body; u += W) d4[u] = make_uint4(z4, z4, z4, z4);
+                const uint32_t t0 = head + (body << 4);
+                if ((uint32_t)tid < lim - t0) dst[t0 + tid] = (uint8_t)z;
+            }
+            // Workgroup-scope release + barrier: the fill of every wave is ordered before the single-byte stores any other
+            // wave of this workgroup issues afterwards to the same lines (one CU, one L1, same-address order; a device-
+            // scope fence here costs 8x the whole kernel, see k4_decode.hip).
+            __threadfence_block();
+            __syncthreads();
+            const bool mine = nsym > 0u && o < lim;
+            if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+                uint32_t e = g << 6;
+                DFA_FRESH(R);
+                uint32_t t = o;
+                const uint32_t cmask = mine ? 7u : 0u, zmask = mine ? 0x18u : 0u;  // switched-off lanes store nothing
+                auto stepS = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int sh = 26 - 4 * (j & 7);
+                    if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
+                    const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
+                    const uint32_t nz = e & zmask;
+                    if (nz != 0u) {  // (one lane in 25 on 1 % noise; the last subsequence of a block may run past lim)
+                        const uint32_t tp = t + ((e >> 14) & 3u);
+                        if (nz == 0x08u) {
+                            if (tp < lim) dst[tp] = (uint8_t)(e >> 16);
+                        } else {
+                            if (t < lim) dst[t] = (uint8_t)(e >> 16);
+                            if (tp < lim) dst[tp] = (uint8_t)(e >> 24);
+                        }
+                    }
+                    t += e & cmask;
+                };
+                [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                    (stepS(std::integral_constant<int, Js>{}), ...);
+                }(std::make_integer_sequence<int, 64>{});
+            }
+            (void)more;
+        } else {
         // ---- phase B: the same walk from the final entry state, two byte stores per step ----
         for (uint32_t cbase = 0; cbase < lim;) {
             uint32_t cc = lim - cbase;
@@ -480,8 +566,8 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
                     const uint32_t nib0 = (R[j >> 3] >> sh0) & 0x3Cu;
                     const uint32_t nib1 = sh1 >= 0 ? ((R[j >> 3] >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                    const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & 0xFFC0u) | nib0));
-                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & 0xFFC0u) | nib1));
+                    const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib0));
+                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & AMASK) | nib1));
                     const uint32_t c0 = e0 & tmask;  // 8 * symbols of the first nibble (bytes past the count are zero)
                     const uint32_t w = ((e >> 16) << c0) | (e0 >> 16);
                     const unsigned long long v = (unsigned long long)w << k8;
@@ -541,16 +627,40 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             DFA_T(7);
             if (cbase < lim) __syncthreads();  // (the next flush reads the bytes carried over)
         }
+        }
         produced += lim;
         entry0 = next_entry;
         wbyte += (unsigned long long)W * 32ull;
         if (exhausted && produced < orig) {
             // The payload is used up but the chunk wants more symbols: the reference keeps reading zero bits
-            // (TableBasedHuffmanDecoder.java:204-208), i.e. the all-zero codeword = first canonical symbol, forever.
+            // (TableBasedHuffmanDecoder.java:204-208).  A codeword that the end of the payload cut (damaged streams only:
+            // the encoder pads to a byte) is completed by those zeros -- the walk below, from the state after the last
+            // subsequence that starts inside the payload; everything after it is the all-zero codeword = first canonical
+            // symbol, forever.  Zeros that leave the code tree are the reference's "decode error at position produced".
             __syncthreads();
-            if ((uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[tid];  // unflushed tail
+            if (!SPARSE && (uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[tid];  // unflushed tail
             const uint8_t z = L.symtab[0];
-            for (uint32_t i = produced + (uint32_t)tid; i < orig; i += W) oblk[i] = z;
+            uint32_t fs = z;
+            if (tid == 0) {
+                const unsigned long long w0 = wbyte - (unsigned long long)W * 32ull;  // this window's first payload byte
+                uint32_t nreal = csize > w0 ? (uint32_t)((csize - w0 + 31ull) >> 5) : 0u;
+                if (nreal > (uint32_t)W) nreal = (uint32_t)W;
+                uint32_t st = nreal ? (uint32_t)L.exits[nreal - 1u] : 0u;
+                while (st != 0u) {
+                    const uint32_t e = L.T[st * 16u];
+                    if ((e & (SPARSE ? 7u : 3u)) != 0u) {  // the cut codeword is complete: it is the nibble's first symbol
+                        fs = (e >> 16) & 0xFFu;            // (SPARSE: a codeword that was under way is never z)
+                        break;
+                    }
+                    st = (e >> 6) & 0xFFu;
+                    if (st == DFA_ERR) {
+                        status = DCZ_E_BADSTREAM;
+                        errpos = (long long)produced;
+                        break;
+                    }
+                }
+            }
+            for (uint32_t i = produced + (uint32_t)tid; i < orig; i += W) oblk[i] = (i == produced) ? (uint8_t)fs : z;
             break;
         }
         __syncthreads();
@@ -573,7 +683,7 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (split_grid) {  // one workgroup per (block, region)
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, true>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, true, false>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, ws.sdesc);
         return;
     }
@@ -581,12 +691,21 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
         const char* e = getenv("DCZ_DFA_FEW_BLOCKS_BELOW");  // tuning knob
         return e ? (uint32_t)atoi(e) : 768u;
     }();
-    if (K >= few_below)  // 4 workgroups of 4 waves per CU
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
+    if (K >= few_below) {  // 4 workgroups of 4 waves per CU
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, false, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+                           d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
+#if DCZ_K4_SPARSE_DFA
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, 0, false, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
-    else  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
-        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+#endif
+    } else {  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
+        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, false, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
+#if DCZ_K4_SPARSE_DFA
+        hipLaunchKernelGGL((k4_dfa<1024, 0, false, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+                           d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
+#endif
+    }
 }
 
 }  // namespace dcz

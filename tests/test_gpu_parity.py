@@ -1220,6 +1220,49 @@ def test_north_star_8gib_uniform_random_1mib_chunks(pkg, svc, orc):
 # The nibble automaton (k4_dfa.hip) on what only it sees differently: incomplete tables (the error state), damage,
 # truncation and requests past the payload in the medium class, in both launch shapes; tables it must hand over (a 1-bit
 # codeword; more than 255 internal nodes) decode through the other kernels with the same results.
+def _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym):
+    """K blocks of nsym (+k) symbols drawn from `syms` with a hand-made length table, some of them damaged, cut short or
+    asked for more symbols than they hold: status, error position and bytes against the oracle."""
+    torch = _torch()
+    codes, _ = orc.canonical_codes(lens)
+    p = None if probs is None else probs / probs.sum()
+    pays, origs, want = [], [], []
+    for k in range(K):
+        data = rng.choice(syms, size=nsym + k, p=p).astype(np.uint8)
+        pay, _ = orc.encode_block(data, lens, codes)
+        pay = pay.copy()
+        n = data.size
+        if k % 7 == 3:
+            pay[int(rng.integers(0, pay.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if k % 11 == 5:
+            pay = pay[: pay.size // 2]
+        if k % 5 == 1:  # cut on a 32-byte boundary, usually inside a codeword: the reference completes it with zero bits
+            pay = pay[: (pay.size * 3 // 4) & ~31]
+        if k % 13 == 6:
+            n += 300
+        try:
+            want.append((0, 0, orc.decode_block(pay, lens, n)))
+        except orc.DecodeError as e:
+            want.append((pkg.native.DCZ_E_BADSTREAM, e.position, None))
+        pays.append(pay)
+        origs.append(n)
+    sizes = np.array([q.size for q in pays], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
+    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
+    stride = (max(origs) + 15) & ~15
+    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
+                                        torch.tensor(origs, dtype=torch.int32, device="cuda"),
+                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
+    torch.cuda.synchronize()
+    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
+    for k, (wst, wpos, wdata) in enumerate(want):
+        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
+        if wst:
+            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
+        else:
+            assert (out[k * stride:k * stride + origs[k]] == wdata).all(), "block %d decodes differently" % k
+
+
 @pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
 @pytest.mark.parametrize("table", ["incomplete", "complete", "one_bit", "deep_chain"])
 def test_medium_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape, table):
@@ -1249,39 +1292,37 @@ def test_medium_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape,
         while sum(2.0 ** -l for l in lens[lens > 0]) > 1.0:
             lens[syms[12 + int(rng.integers(0, 18))]] += 1
         probs = np.r_[np.full(12, 1e-4), np.full(18, 1.0)]
-    codes, _ = orc.canonical_codes(lens)
-    p = None if probs is None else probs / probs.sum()
     K, nsym = (800, 5000) if shape == "many_blocks" else (12, 70000)
-    pays, origs, want = [], [], []
-    for k in range(K):
-        data = rng.choice(syms, size=nsym + k, p=p).astype(np.uint8)
-        pay, _ = orc.encode_block(data, lens, codes)
-        pay = pay.copy()
-        n = data.size
-        if k % 7 == 3:
-            pay[int(rng.integers(0, pay.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
-        if k % 11 == 5:
-            pay = pay[: pay.size // 2]
-        if k % 13 == 6:
-            n += 300
-        try:
-            want.append((0, 0, orc.decode_block(pay, lens, n)))
-        except orc.DecodeError as e:
-            want.append((pkg.native.DCZ_E_BADSTREAM, e.position, None))
-        pays.append(pay)
-        origs.append(n)
-    sizes = np.array([q.size for q in pays], dtype=np.int32)
-    offs = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]).astype(np.int64)
-    payload = torch.from_numpy(np.concatenate(pays + [np.zeros(16, np.uint8)])).cuda()
-    stride = (max(origs) + 15) & ~15
-    out, st, ep = svc.decompress_device(payload, torch.from_numpy(offs).cuda(), torch.from_numpy(sizes).cuda(),
-                                        torch.tensor(origs, dtype=torch.int32, device="cuda"),
-                                        torch.from_numpy(np.tile(lens.astype(np.uint8), (K, 1))).cuda(), stride)
-    torch.cuda.synchronize()
-    st, ep, out = st.cpu().numpy(), ep.cpu().numpy(), out.cpu().numpy()
-    for k, (wst, wpos, wdata) in enumerate(want):
-        assert st[k] == wst, "block %d: status %d, oracle %d" % (k, st[k], wst)
-        if wst:
-            assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
-        else:
-            assert (out[k * stride:k * stride + origs[k]] == wdata).all(), "block %d decodes differently" % k
+    _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym)
+
+
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
+@pytest.mark.parametrize("table", ["pairs", "incomplete", "deep", "many_symbols", "not_sparse"])
+def test_sparse_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape, table):
+    """Blocks dominated by a 1-bit symbol (k4_dfa's SPARSE instantiation: up to four symbols per nibble, two of them
+    other than the 1-bit one) and the tables it leaves to k4_decode's short-code kernel."""
+    rng = np.random.default_rng({"pairs": 11, "incomplete": 12, "deep": 13, "many_symbols": 14, "not_sparse": 15}[table])
+    lens = np.zeros(256, np.int32)
+    if table == "pairs":       # 2-bit and 3-bit neighbours: nibbles that complete two symbols other than the 1-bit one
+        syms = np.array([0x41, 0x00, 0x7F, 0xFE])
+        lens[syms] = [2, 1, 3, 3]
+        probs = np.array([0.05, 0.90, 0.025, 0.025])
+    elif table == "incomplete":  # Kraft sum < 1: damage meets patterns without a codeword
+        syms = np.array([0xAA, 3, 200])
+        lens[syms] = [1, 3, 4]
+        probs = np.array([0.96, 0.03, 0.01])
+    elif table == "deep":      # a chain of codewords down to 24 bits
+        syms = np.arange(10, 10 + 24)
+        lens[syms] = np.r_[np.arange(1, 24), 23]
+        probs = np.r_[0.97, np.full(23, 0.03 / 23)]
+    elif table == "many_symbols":  # the 1-bit symbol + 255 codewords of 9 bits: > 255 internal nodes, not the automaton's
+        syms = np.arange(256)
+        lens[:] = 9
+        lens[0] = 1
+        probs = np.r_[0.97, np.full(255, 0.03 / 255)]
+    else:                      # a 1-bit symbol that is not dominant enough (>= 1.3 bits per symbol): multi-symbol tables
+        syms = np.array([0, 1, 2, 3])
+        lens[syms] = [1, 2, 3, 3]
+        probs = np.array([0.6, 0.2, 0.1, 0.1])
+    K, nsym = (800, 60000) if shape == "many_blocks" else (12, 700000)
+    _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym)
