@@ -38,12 +38,19 @@ namespace dcz {
 #ifndef DCZ_DFA_HOIST
 #define DCZ_DFA_HOIST 1  // 1: the 64 nibble offsets of a subsequence are computed once per window and kept in registers
 #endif                   // (1 vector instruction per walk step, ~120 VGPRs); 0: recomputed in every walk (3 per step, ~50 VGPRs)
-#if DCZ_DFA_HOIST
+// The nibbles of subsequence dwords >= HOIST_DW are extracted where they are used, not once per window: the instantiations
+// that would spill otherwise (regions, 1024 threads) give up the last dword(s) -- a spill reload is a load, and on gfx950 a
+// load waits for every older store of the wave.
 #define DFA_FRESH(R) do { } while (0)
-#define DFA_FRESH1(r) do { } while (0)
-#else
-#define DFA_FRESH(R) do { } while (0)
-#define DFA_FRESH1(r) asm volatile("" : "+v"(r))  // the nibbles of this dword are extracted here, not before
+#define DFA_FRESH1(r)                                            \
+    do {                                                         \
+        if constexpr ((j >> 3) >= HOIST_DW) asm volatile("" : "+v"(r)); \
+    } while (0)
+#ifndef DCZ_DFA_HOIST_DW_SPLIT
+#define DCZ_DFA_HOIST_DW_SPLIT 4
+#endif
+#ifndef DCZ_DFA_HOIST_DW_1024
+#define DCZ_DFA_HOIST_DW_1024 5
 #endif
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
     uint8_t* __restrict__ d_cls, const SplitDesc* __restrict__ sdp) {
     using LdsT = DfaLds<W, OC>;
+    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : 8;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
