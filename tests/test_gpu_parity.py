@@ -297,6 +297,7 @@ def test_generators_match_oracle(pkg, svc, orc):
     lib, h = pkg.lib(), svc.ctx.handle
     for n, start in [(1, 0), (17, 4), (4096, 0), (100003, 1 << 20), (1 << 20, 12)]:
         t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # (torch's fill runs on torch's stream, the generators on the context's)
         assert lib.dczu_fill_java_random(h, t.data_ptr(), n, 42, start, None) == 0
         torch.cuda.synchronize()
         assert (t.cpu().numpy() == orc.java_random_bytes(42, start + n)[start:]).all()
