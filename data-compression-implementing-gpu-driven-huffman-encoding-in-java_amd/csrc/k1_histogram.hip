@@ -22,7 +22,8 @@ namespace dcz {
 #define DCZ_K1_COPIES 16
 #endif
 #ifndef DCZ_K1_NT
-#define DCZ_K1_NT 0  // measured: no difference (K1 is bound by its LDS atomics at ~5.6 TB/s, not by the loads)
+#define DCZ_K1_NT 1  // read-once stream: non-temporal loads.  With the next step's loads issued ahead: 0.79 -> 0.72 ms per
+                     // 4 GiB (6.0 TB/s); without that, and for 4 instead of 6 vector instructions per byte, no difference
 #endif
 #ifndef DCZ_K1_WAVES
 #define DCZ_K1_WAVES 4
@@ -38,11 +39,27 @@ __device__ __forceinline__ void hist_add(uint32_t* h, uint32_t col, uint32_t byt
     __hip_atomic_fetch_add(&h[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// Four bytes of a dword, 4 vector instructions + 1 LDS atomic each (the kernel is vector-issue bound: 6 per byte measured
+// 0.80 ms per 4 GiB, 4 per byte see DESIGN.md): bit field extract of the low 7 bits, shift-add onto the lane's column
+// address; bit field extract of bit 7, multiply-add to 1 or 0x10000.
+template <int K>
+__device__ __forceinline__ void hist_add_byte(uint32_t hcol_addr, uint32_t d) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // (inline assembly: the optimiser rewrites the C forms of these into shift + and + add and and + compare + select)
+    uint32_t t, addr, b, val;
+    asm("v_bfe_u32 %0, %1, %2, 7" : "=v"(t) : "v"(d), "n"(8 * K));
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "n"(K1_CSHIFT + 2), "v"(hcol_addr));
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(b) : "v"(d), "n"(8 * K + 7));
+    asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(val) : "v"(b), "s"(0xFFFFu));
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 __device__ __forceinline__ void hist_add_dword(uint32_t* h, uint32_t col, uint32_t d) {
-    hist_add(h, col, d & 0xFFu);
-    hist_add(h, col, (d >> 8) & 0xFFu);
-    hist_add(h, col, (d >> 16) & 0xFFu);
-    hist_add(h, col, d >> 24);
+    const uint32_t hcol_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(h + col));
+    hist_add_byte<0>(hcol_addr, d);
+    hist_add_byte<1>(hcol_addr, d);
+    hist_add_byte<2>(hcol_addr, d);
+    hist_add_byte<3>(hcol_addr, d);
 }
 
 __device__ __forceinline__ void hist_add_vec(uint32_t* h, uint32_t col, const uint4& v) {
@@ -86,37 +103,41 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
     const uint4* pv = reinterpret_cast<const uint4*>(p + nhead);
     const uint32_t nvec = (len - nhead) >> 4;
 
-    // body: 4 x 16 B per lane in flight per step
-    for (uint32_t base = 0; base < nvec; base += 256) {
-        const uint32_t i0 = base + (uint32_t)lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
-        uint4 d0, d1, d2, d3;
-        if (base + 256 <= nvec) {
+    // body: 4 x 16 B per lane per step, the next step's loads issued before this step's atomics (a wave alternates between
+    // waiting for HBM and feeding the LDS otherwise, and only five waves per SIMD are there to cover for it)
+    auto load4 = [&](uint32_t base, uint4& d0, uint4& d1, uint4& d2, uint4& d3) {
+        const uint32_t i0 = base + (uint32_t)lane;
 #if DCZ_K1_NT
-            // read-once stream: non-temporal loads (copybench: 7.1 TB/s against 6.2-6.3 TB/s for plain loads)
-            const u32x4* pn = reinterpret_cast<const u32x4*>(pv);
-            const u32x4 n0 = __builtin_nontemporal_load(pn + i0), n1 = __builtin_nontemporal_load(pn + i1);
-            const u32x4 n2 = __builtin_nontemporal_load(pn + i2), n3 = __builtin_nontemporal_load(pn + i3);
-            d0 = make_uint4(n0.x, n0.y, n0.z, n0.w);
-            d1 = make_uint4(n1.x, n1.y, n1.z, n1.w);
-            d2 = make_uint4(n2.x, n2.y, n2.z, n2.w);
-            d3 = make_uint4(n3.x, n3.y, n3.z, n3.w);
+        const u32x4* pn = reinterpret_cast<const u32x4*>(pv);
+        const u32x4 n0 = __builtin_nontemporal_load(pn + i0), n1 = __builtin_nontemporal_load(pn + i0 + 64);
+        const u32x4 n2 = __builtin_nontemporal_load(pn + i0 + 128), n3 = __builtin_nontemporal_load(pn + i0 + 192);
+        d0 = make_uint4(n0.x, n0.y, n0.z, n0.w);
+        d1 = make_uint4(n1.x, n1.y, n1.z, n1.w);
+        d2 = make_uint4(n2.x, n2.y, n2.z, n2.w);
+        d3 = make_uint4(n3.x, n3.y, n3.z, n3.w);
 #else
-            d0 = pv[i0];
-            d1 = pv[i1];
-            d2 = pv[i2];
-            d3 = pv[i3];
+        d0 = pv[i0];
+        d1 = pv[i0 + 64];
+        d2 = pv[i0 + 128];
+        d3 = pv[i0 + 192];
 #endif
-            hist_add_vec(h, col, d0);
-            hist_add_vec(h, col, d1);
-            hist_add_vec(h, col, d2);
-            hist_add_vec(h, col, d3);
-        } else {
-            if (i0 < nvec) { d0 = pv[i0]; hist_add_vec(h, col, d0); }
-            if (i1 < nvec) { d1 = pv[i1]; hist_add_vec(h, col, d1); }
-            if (i2 < nvec) { d2 = pv[i2]; hist_add_vec(h, col, d2); }
-            if (i3 < nvec) { d3 = pv[i3]; hist_add_vec(h, col, d3); }
-        }
+    };
+    const uint32_t nfull = nvec & ~255u;  // whole steps
+    uint4 c0, c1, c2, c3;
+    if (nfull) load4(0, c0, c1, c2, c3);
+    for (uint32_t base = 0; base < nfull; base += 256) {
+        uint4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+        if (base + 256 < nfull) load4(base + 256, n0, n1, n2, n3);
+        hist_add_vec(h, col, c0);
+        hist_add_vec(h, col, c1);
+        hist_add_vec(h, col, c2);
+        hist_add_vec(h, col, c3);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
     }
+    for (uint32_t i = nfull + (uint32_t)lane; i < nvec; i += 64) hist_add_vec(h, col, pv[i]);  // the ragged last step
     // tail (< 16 bytes)
     {
         const uint32_t done = nhead + (nvec << 4);
