@@ -47,20 +47,41 @@ struct SplitDesc {
     uint32_t* exit;    // bits from the region's end to the first codeword past it, 0xFFFFFFFF = not usable
     uint32_t* off;     // output offset of the region inside its chunk
     uint32_t* nreg;    // [block] regions in use, 0 = the block is not split
+    uint32_t* rbase;   // [block + 1] first workgroup of the block's regions in the region grids (k4_split_setup)
     uint32_t rmax;
-    uint32_t pad;
+    uint32_t nblk;     // blocks of the call
     unsigned long long region_bytes;
 };
+// Region grids are one-dimensional and dense: workgroup i serves region i - rbase[b] of the block b with
+// rbase[b] <= i < rbase[b + 1] (a [block][rmax] grid launched 30x more workgroups than there are regions: 0.09 ms per
+// launch for 32 chunks of 32 MiB).  SPLIT_GRID workgroups cover any call: sum ceil((csize + 15) / S) <= REGIONS + 2 * blocks.
+__device__ __forceinline__ bool split_region_of(const SplitDesc* sdp, uint32_t i, uint32_t& b, uint32_t& reg) {
+    const uint32_t n = sdp->nblk;
+    const uint32_t* rb = sdp->rbase;
+    if (i >= rb[n]) return false;
+    uint32_t lo = 0, hi = n;  // rb[lo] <= i < rb[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rb[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    b = lo;
+    reg = i - rb[lo];
+    return true;
+}
 constexpr size_t SPLIT_MAX_BLOCKS = 128;      // blocks per call below which a call may be split
 constexpr size_t SPLIT_REGIONS = 2048;        // regions aimed at per call
 constexpr size_t SPLIT_ENTRIES = SPLIT_MAX_BLOCKS * (SPLIT_REGIONS + 2);
+constexpr uint32_t SPLIT_GRID = (uint32_t)(SPLIT_REGIONS + 2 * SPLIT_MAX_BLOCKS);
 // Workspace of one decode call (device memory, see decode_ws_bytes).
 struct DecodeWs {
     uint8_t* cls;        // K x u8: class byte of every block (k4_classify, then the probe launch / k4_split_scan)
     SplitDesc* sdesc;    // device copy of the region table descriptor of this call
-    uint32_t* split;     // 4 x SPLIT_ENTRIES + SPLIT_MAX_BLOCKS u32
+    uint32_t* split;     // 4 x SPLIT_ENTRIES + SPLIT_MAX_BLOCKS + (SPLIT_MAX_BLOCKS + 1) u32
 };
-inline size_t decode_ws_bytes(size_t K) { return ((K + 255) & ~(size_t)255) + 256 + (4 * SPLIT_ENTRIES + SPLIT_MAX_BLOCKS) * 4; }
+inline size_t decode_ws_bytes(size_t K) {
+    return ((K + 255) & ~(size_t)255) + 256 + (4 * SPLIT_ENTRIES + 2 * SPLIT_MAX_BLOCKS + 4) * 4;
+}
 inline DecodeWs decode_ws_at(void* base, size_t K) {
     uint8_t* p = static_cast<uint8_t*>(base);
     const size_t kb = (K + 255) & ~(size_t)255;

@@ -409,9 +409,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
                                        // that the per-block kernels keep their register allocation
     uint32_t reg = 0;
     if constexpr (split) {
-        const uint32_t rmax = sdp->rmax;
-        b = blockIdx.x / rmax;
-        reg = blockIdx.x - b * rmax;
+        if (!split_region_of(sdp, blockIdx.x, b, reg)) return;
         if (d_slow[b] != 2 || reg >= sdp->nreg[b]) return;  // workgroup-uniform
     } else if constexpr (MODE == 1) {
         if (d_slow[b] != 1) return;  // workgroup-uniform: only the blocks the probe flagged
@@ -1286,10 +1284,11 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
             sd.exit = ws.split + 2 * SPLIT_ENTRIES;
             sd.off = ws.split + 3 * SPLIT_ENTRIES;
             sd.nreg = ws.split + 4 * SPLIT_ENTRIES;
-            sd.pad = 0;
+            sd.rbase = ws.split + 4 * SPLIT_ENTRIES + SPLIT_MAX_BLOCKS;
+            sd.nblk = K;
             launch_split_count(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, d_slow, d_status, d_errpos, sd,
                                ws.sdesc, s);
-            const uint32_t grid = K * sd.rmax;
+            const uint32_t grid = SPLIT_GRID;
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 3);
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 3);
 #if DCZ_K4_MEDIUM_DFA

@@ -156,9 +156,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     unsigned long long plast = clock64();
 #endif
     if constexpr (SPLIT) {
-        const uint32_t rmax = sdp->rmax;
-        b = blockIdx.x / rmax;
-        reg = blockIdx.x - b * rmax;
+        if (!split_region_of(sdp, blockIdx.x, b, reg)) return;
         if (d_cls[b] != 2 || reg >= sdp->nreg[b]) return;  // workgroup-uniform
     } else {
         if (d_cls[b] != 0) return;  // fixed-length, exact-entry, split or rejected block (workgroup-uniform)

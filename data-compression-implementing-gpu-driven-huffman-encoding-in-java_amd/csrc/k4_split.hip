@@ -84,7 +84,8 @@ __global__ __launch_bounds__(SP_W) void k4_split_count(const uint8_t* __restrict
     constexpr int TBJ = DCZ_SP_TBJ;
     constexpr int W = SP_W;
     __shared__ SpLds<TBJ> L;
-    const uint32_t b = blockIdx.y, r = blockIdx.x;
+    uint32_t b, r;
+    if (!split_region_of(sdp, blockIdx.x, b, r)) return;  // workgroup-uniform
     const int tid = (int)threadIdx.x;
     if (d_cls[b] != 0) return;  // fixed-length or rejected block (workgroup-uniform)
     const SplitDesc sd = *sdp;  // (region size chosen on the device from the payload bytes this call really has)
@@ -388,22 +389,35 @@ __global__ __launch_bounds__(256) void k4_split_scan(const unsigned long long* _
 
 // Region size for this call: the payload bytes of the blocks that can be split / SPLIT_REGIONS, at least 64 KiB, whole
 // windows; written with the table pointers to the device copy of the descriptor every consumer reads.
-__global__ void k4_split_setup(SplitDesc* dst, SplitDesc v, const uint32_t* __restrict__ d_comp_size,
+__global__ void k4_split_setup(SplitDesc* dst, SplitDesc v, const uint8_t* __restrict__ comp,
+                               const unsigned long long* __restrict__ d_comp_off, const uint32_t* __restrict__ d_comp_size,
                                const uint8_t* __restrict__ d_cls, uint32_t K) {
     unsigned long long total = 0;
     for (uint32_t b = 0; b < K; b++)
         if (d_cls[b] == 0) total += d_comp_size[b];
     unsigned long long S = (total + SPLIT_REGIONS - 1) / SPLIT_REGIONS;
     if (S < 65536ull) S = 65536ull;
-    v.region_bytes = (S + 8191ull) & ~8191ull;
+    v.region_bytes = S = (S + 8191ull) & ~8191ull;
+    // workgroups of the region grids: the regions of every block that can be split (what k4_split_count computes)
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < K; b++) {
+        v.rbase[b] = acc;
+        if (d_cls[b] != 0) continue;
+        const unsigned long long skew = ((uintptr_t)comp + (uintptr_t)d_comp_off[b]) & 15u;
+        const unsigned long long nreg = (skew + d_comp_size[b] + S - 1) / S;
+        if (nreg >= 2 && nreg <= v.rmax) acc += (uint32_t)nreg;
+    }
+    v.rbase[K] = acc;
+    v.nblk = K;
     *dst = v;
 }
 
 void launch_split_count(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                         const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, uint8_t* d_cls, int32_t* d_status,
                         int64_t* d_errpos, const SplitDesc& sd, SplitDesc* d_sd, hipStream_t s) {
-    hipLaunchKernelGGL(k4_split_setup, dim3(1), dim3(1), 0, s, d_sd, sd, d_comp_size, d_cls, K);
-    hipLaunchKernelGGL(k4_split_count, dim3(sd.rmax, K), dim3(SP_W), 0, s, d_comp,
+    hipLaunchKernelGGL(k4_split_setup, dim3(1), dim3(1), 0, s, d_sd, sd, d_comp,
+                       reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_cls, K);
+    hipLaunchKernelGGL(k4_split_count, dim3(SPLIT_GRID), dim3(SP_W), 0, s, d_comp,
                        reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_len, d_cls, d_sd);
     hipLaunchKernelGGL(k4_split_scan, dim3(K), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_comp_off),
                        d_comp_size, d_orig_size, d_comp, d_cls, d_status, reinterpret_cast<long long*>(d_errpos), d_sd);
