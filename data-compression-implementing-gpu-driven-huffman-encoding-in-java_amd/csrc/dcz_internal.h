@@ -37,6 +37,15 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
 
 // K4: decode.  Region table of the split decoder (k4_split.hip): a block cut into regions of region_bytes of payload,
 // one workgroup per region; the arrays are [block][rmax].
+#ifndef DCZ_K4_MEDIUM_DFA
+#define DCZ_K4_MEDIUM_DFA 1  // medium class: k4_dfa.hip decodes (and, for split blocks, counts) the tables it can take
+#endif
+#ifndef DCZ_K4_CLS2_A
+#define DCZ_K4_CLS2_A 4  // class boundary medium / short codes: medium when orig * A <= csize * B (>= 8 * A / B bits/symbol)
+#endif
+#ifndef DCZ_K4_CLS2_B
+#define DCZ_K4_CLS2_B 9
+#endif
 #ifndef DCZ_K4_SPARSE_DFA
 #define DCZ_K4_SPARSE_DFA 1  // sparse short-code blocks (one 1-bit symbol, < 1.3 bits/symbol): k4_dfa's SPARSE instantiation
 #endif
@@ -94,6 +103,8 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
 void launch_classify(const uint8_t* d_len, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                      const uint32_t* d_orig_size, size_t comp_bytes, size_t out_stride, uint32_t K, const DecodeWs& ws,
                      int32_t* d_status, int64_t* d_errpos, hipStream_t s);
+void launch_count_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                      const uint32_t* d_orig_size, const uint8_t* d_len, uint8_t* d_cls, const SplitDesc* d_sd, hipStream_t s);
 void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                          const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
                          const DecodeWs& ws, hipStream_t s);

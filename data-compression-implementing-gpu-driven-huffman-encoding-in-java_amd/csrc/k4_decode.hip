@@ -470,7 +470,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
                 ni = (L.cnt[l + 1] + ni + 1u) / 2u;
                 states += ni;
             }
-            L.dfa_takes = (L.cnt[1] == 0u && states <= (MODE == 3 ? 253u : 255u) && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
+            L.dfa_takes = (L.cnt[1] == 0u && states <= 255u && mx > 0u && kraft <= (1ull << 32)) ? 1u : 0u;
         }
 #endif
 #if DCZ_K4_SPARSE_DFA

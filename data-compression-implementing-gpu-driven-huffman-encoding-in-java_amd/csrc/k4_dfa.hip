@@ -47,7 +47,7 @@ namespace dcz {
         if constexpr ((j >> 3) >= HOIST_DW) asm volatile("" : "+v"(r)); \
     } while (0)
 #ifndef DCZ_DFA_HOIST_DW_SPLIT
-#define DCZ_DFA_HOIST_DW_SPLIT 4
+#define DCZ_DFA_HOIST_DW_SPLIT 3
 #endif
 #ifndef DCZ_DFA_HOIST_DW_1024
 #define DCZ_DFA_HOIST_DW_1024 5
@@ -138,13 +138,21 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 // Walks are the same (entry/exit states, fixed point, scan of the counts); the output pass has no tile: the window's
 // output range is filled with z by 16-byte stores and the walk stores the other symbols as single bytes straight to
 // global memory (the scheme of k4_decode.hip's sparse path, whose table walk this replaces: 4.25 -> see DESIGN.md).
-template <int W, int OC, bool SPLIT, bool SPARSE>
+// MODE 0: one workgroup per block.  MODE 1 (SPLIT): one workgroup per REGION of a block that has been cut up, entry state,
+// output offset and symbol count from the region table.  MODE 2 (COUNT): the counting pass that fills that table for the
+// blocks this automaton takes (k4_split.hip's jump walk does it for the others): regions are S payload bytes, the
+// workgroup of region r > 0 first walks the window in front of its region from the guess "codeword boundary" -- the
+// state it arrives in at the region's first byte is the region's entry --, then walks its region window by window
+// (rounds of phase A only) and reports (entry state, symbols completed inside the region, exit state).
+// k4_split_scan proves the chain exit(r-1) == entry(r): equal states at the same byte are the same parse from there on.
+template <int W, int OC, int MODE, bool SPARSE>
 __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
     uint8_t* __restrict__ d_cls, const SplitDesc* __restrict__ sdp) {
     using LdsT = DfaLds<W, OC>;
+    constexpr bool SPLIT = MODE == 1, COUNT = MODE == 2;
     constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : 8;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -158,14 +166,22 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     if constexpr (SPLIT) {
         if (!split_region_of(sdp, blockIdx.x, b, reg)) return;
         if (d_cls[b] != 2 || reg >= sdp->nreg[b]) return;  // workgroup-uniform
+    } else if constexpr (COUNT) {
+        if (!split_region_of(sdp, blockIdx.x, b, reg)) return;
+        if (d_cls[b] != 0) return;  // fixed-length or rejected block
     } else {
         if (d_cls[b] != 0) return;  // fixed-length, exact-entry, split or rejected block (workgroup-uniform)
     }
     const uint32_t orig_blk = d_orig_size[b];
     const unsigned long long coff = d_comp_off[b];
     const uint32_t csize = d_comp_size[b];
+    if constexpr (COUNT) {  // the regions k4_split_scan expects of this block (k4_split_count's rule)
+        const unsigned long long S = sdp->region_bytes;
+        const unsigned long long nreg = ((((uintptr_t)comp + (uintptr_t)coff) & 15u) + csize + S - 1) / S;
+        if (nreg < 2 || reg >= nreg || nreg > sdp->rmax) return;
+    }
     // symbols this workgroup produces: the whole chunk, or what k4_split_scan gave its region
-    const uint32_t orig = SPLIT ? sdp->count[(uint64_t)b * sdp->rmax + reg] : orig_blk;
+    const uint32_t orig = SPLIT ? sdp->count[(uint64_t)b * sdp->rmax + reg] : COUNT ? 0xFFFFFFFFu : orig_blk;
     if (SPLIT && orig == 0u) return;
     {
         const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig_blk * 13ull;
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     }
     __syncthreads();
     if (L.bad_table) {
-        if (tid == 0) {
+        if (!COUNT && tid == 0) {  // (COUNT: k4_split_count marks the regions of such a block unusable)
             d_status[b] = DCZ_E_BADTABLE;
             if (d_errpos) d_errpos[b] = 0;
         }
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     if constexpr (SPARSE) {  // (k4_decode.hip's short-code kernel applies the same test and leaves the block alone)
         if (L.cnt[1] != 1u || L.nstates > 255u || L.maxlen < 2u) return;
     } else {
-        if (L.cnt[1] != 0u || L.nstates > (SPLIT ? 253u : 255u) || L.maxlen == 0u) return;
+        if (L.cnt[1] != 0u || L.nstates > 255u || L.maxlen == 0u) return;
     }
     for (int sy = tid; sy < 256; sy += W) {
         const uint32_t l = L.len8[sy];
@@ -310,37 +326,21 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     uint32_t produced = 0, gpos = 0, ocarry = hskip;
     uint32_t entry0 = 0;  // state at the first nibble of the window (the block starts at the root)
     unsigned long long wbyte = 0;  // payload byte of the window's first subsequence
-    if constexpr (SPLIT) {
-        // The region's proven entry is a BIT (first codeword boundary at or past the region start).  The walk starts at
-        // the byte that holds it; two extra table rows bring lane 0 from there to the automaton proper:
-        //   row ENT: the nibble that holds the entry bit -- only its bits from the entry on are walked, from the root;
-        //   row SKIP: a nibble that lies wholly before the entry bit: any input leads to ENT (or the root), no symbol.
-        const unsigned long long ebit = 8ull * reg * sdp->region_bytes + sdp->entry[(uint64_t)b * sdp->rmax + reg] - 8ull * skew;
-        wbyte = ebit >> 3;
-        const uint32_t xb = (uint32_t)(ebit & 7ull), kskip = xb >> 2, rb = xb & 3u;
-        const uint32_t ENT = L.nstates, SKIP = L.nstates + 1u;
-        __syncthreads();  // (T's regular rows are written)
-        if (tid < 16) {
-            const uint32_t nib = (uint32_t)tid;
-            uint32_t l = 0, p = 0, c = 0, syms = 0;
-            bool err = false;
-            for (int i = 3 - (int)rb; i >= 0 && !err; i--) {
-                p = 2u * p + ((nib >> i) & 1u);
-                l++;
-                const uint32_t rel = p - L.first[l];
-                if (rel < L.cnt[l]) {
-                    syms |= (uint32_t)L.symtab[L.offs[l] + rel] << (8 * c);
-                    c++;
-                    l = 0;
-                    p = 0;
-                } else if (rel - L.cnt[l] >= L.nint[l]) {
-                    err = true;
-                }
-            }
-            L.T[ENT * 16u + nib] = ((err ? DFA_ERR : L.base[l] + (p - L.first[l] - L.cnt[l])) << 6) | c | (c << 3) | (syms << 16);
-            L.T[SKIP * 16u + nib] = (rb ? ENT : 0u) << 6;
+    uint32_t nwin = 0xFFFFFFFFu;  // COUNT: windows still to walk, the one in front of the region included
+    bool preroll = false;
+    if constexpr (SPLIT) {  // the region's proven entry: the automaton's state at its first payload byte
+        wbyte = (unsigned long long)reg * sdp->region_bytes;
+        entry0 = sdp->entry[(uint64_t)b * sdp->rmax + reg];
+    }
+    if constexpr (COUNT) {
+        const unsigned long long S = sdp->region_bytes;
+        nwin = (uint32_t)(S / ((unsigned long long)W * 32ull));  // (S is a multiple of 8 KiB)
+        wbyte = (unsigned long long)reg * S;
+        if (reg > 0) {
+            wbyte -= (unsigned long long)W * 32ull;
+            nwin++;
+            preroll = true;
         }
-        entry0 = kskip ? SKIP : (rb ? ENT : 0u);
     }
     int status = DCZ_OK;
     long long errpos = 0;
@@ -358,13 +358,16 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     // (lanes are 32 bytes apart, windows W * 32)
     const uint32_t sk2 = (skew + (uint32_t)(wbyte & 15ull)) & 15u;
     const uint32_t sq = sk2 >> 2, sr = sk2 & 3u;
-    if (orig > 0) prefetch(wbyte);
+    if (orig > 0 && wbyte < csize) prefetch(wbyte);
     for (uint32_t i = (uint32_t)tid; i < (uint32_t)(sizeof(L.tile) / 16u); i += W)  // phase B ORs into the tile
         reinterpret_cast<uint4*>(L.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();  // T complete
     DFA_T(0);
 
-    while (produced < orig) {
+    uint32_t rentry = 0, wexit = 0;  // COUNT: the region's entry state; every mode: state after the window's last subsequence
+    unsigned long long rcount = 0;   // COUNT: symbols completed inside the region
+    bool unusable = false;           // COUNT: the region cannot be proven (left the code tree, no fixed point)
+    while (COUNT ? nwin != 0u : produced < orig) {
 #if DCZ_K4_PROF
         pacc[8]++;
 #endif
@@ -455,9 +458,15 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             g = ng;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull && (tid & 63) == 0) L.flag[(round + 1u) % 3u] = 1;
             round++;
-            if constexpr (!SPLIT && !SPARSE) {  // (a proven region and a sparse block simply keep iterating: at most W rounds)
+            if constexpr (MODE == 0 && !SPARSE) {  // (a proven region and a sparse block simply keep iterating: at most W rounds)
                 if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // workgroup-uniform: this block does not self-synchronise
                     if (tid == 0) d_cls[b] = 1;                // the exact-entry launch (k4_decode.hip, MODE 1) decodes it
+                    return;
+                }
+            }
+            if constexpr (COUNT) {
+                if (round == (uint32_t)DCZ_K4_EXACT_AFTER) {  // no fixed point: the block stays with the per-block kernels
+                    if (tid == 0) sdp->exit[(uint64_t)b * sdp->rmax + reg] = 0xFFFFFFFFu;
                     return;
                 }
             }
@@ -469,8 +478,34 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         const uint32_t o = dfa_block_scan<W>(nsym, L, tw);
         const uint32_t remaining = orig - produced;
         if (bad) atomicMin(&L.err_idx, o + nsym);  // (the error state completes no symbol: nsym = symbols before it)
-        const uint32_t next_entry = L.exits[W - 1];
+        // state after the last subsequence that starts inside the payload (the window's entry if none does)
+        {
+            uint32_t nreal = csize > wbyte ? (uint32_t)((csize - wbyte + 31ull) >> 5) : 0u;
+            if (nreal > (uint32_t)W) nreal = (uint32_t)W;
+            wexit = nreal ? (uint32_t)L.exits[nreal - 1u] : entry0;
+        }
+        const uint32_t next_entry = wexit;
         __syncthreads();
+        if constexpr (COUNT) {
+            // nothing is decoded: add up, move on.  A subsequence of the region that left the code tree makes the region
+            // unusable (the per-block kernels then report the error position); in the window in front of the region only
+            // the state it ends in matters.
+            if (preroll) {
+                rentry = wexit;
+                preroll = false;
+            } else {
+                rcount += tw;
+                if (L.err_idx != 0xFFFFFFFFu) unusable = true;
+            }
+            __syncthreads();
+            if (tid == 0) L.err_idx = 0xFFFFFFFFu;
+            entry0 = wexit;
+            wbyte += (unsigned long long)W * 32ull;
+            nwin--;
+            if (exhausted) break;
+            __syncthreads();
+            continue;
+        }
         const uint32_t err_idx = L.err_idx;
         if (err_idx < remaining) {
             status = DCZ_E_BADSTREAM;
@@ -648,10 +683,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             const uint8_t z = L.symtab[0];
             uint32_t fs = z;
             if (tid == 0) {
-                const unsigned long long w0 = wbyte - (unsigned long long)W * 32ull;  // this window's first payload byte
-                uint32_t nreal = csize > w0 ? (uint32_t)((csize - w0 + 31ull) >> 5) : 0u;
-                if (nreal > (uint32_t)W) nreal = (uint32_t)W;
-                uint32_t st = nreal ? (uint32_t)L.exits[nreal - 1u] : 0u;
+                uint32_t st = wexit;
                 while (st != 0u) {
                     const uint32_t e = L.T[st * 16u];
                     if ((e & (SPARSE ? 7u : 3u)) != 0u) {  // the cut codeword is complete: it is the nibble's first symbol
@@ -672,6 +704,16 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         __syncthreads();
     }
 
+    if constexpr (COUNT) {
+        if (tid == 0) {
+            const uint64_t i = (uint64_t)b * sdp->rmax + reg;
+            const bool bad = unusable || wexit == DFA_ERR || rentry == DFA_ERR;
+            sdp->entry[i] = rentry;
+            sdp->count[i] = (uint32_t)(rcount > 0xFFFFFFFFull ? 0xFFFFFFFFull : rcount);
+            sdp->exit[i] = bad ? 0xFFFFFFFFu : wexit;
+        }
+        return;
+    }
     if (tid == 0 && (!SPLIT || status != DCZ_OK)) {  // (a split block got its status from k4_split_scan)
         d_status[b] = status;
         if (d_errpos) d_errpos[b] = errpos + (SPLIT ? (long long)sdp->off[(uint64_t)b * sdp->rmax + reg] : 0ll);
@@ -682,6 +724,14 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
 #endif
 }
 
+// counting pass of the split decoder for the blocks the automaton takes (between k4_split_setup and k4_split_scan)
+void launch_count_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
+                      const uint32_t* d_orig_size, const uint8_t* d_len, uint8_t* d_cls, const SplitDesc* d_sd, hipStream_t s) {
+    hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, 0, 2, false>), dim3(SPLIT_GRID), dim3(DCZ_DFA_W), 0, s, d_comp,
+                       reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size, d_len, (size_t)0,
+                       (uint8_t*)nullptr, (int32_t*)nullptr, (long long*)nullptr, d_cls, d_sd);
+}
+
 void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                        const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
                        int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, uint32_t split_grid, hipStream_t s) {
@@ -689,7 +739,7 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (split_grid) {  // one workgroup per (block, region)
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, true, false>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, 1, false>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, ws.sdesc);
         return;
     }
@@ -698,17 +748,17 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
         return e ? (uint32_t)atoi(e) : 768u;
     }();
     if (K >= few_below) {  // 4 workgroups of 4 waves per CU
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, false, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, 0, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, 0, false, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, 0, 0, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #endif
     } else {  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
-        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, false, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, 0, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
-        hipLaunchKernelGGL((k4_dfa<1024, 0, false, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<1024, 0, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #endif
     }

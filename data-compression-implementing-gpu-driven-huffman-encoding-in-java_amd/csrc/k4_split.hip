@@ -79,6 +79,7 @@ __device__ __attribute__((noinline)) uint32_t sp_slow_len(const LdsT& L, uint32_
 __global__ __launch_bounds__(SP_W) void k4_split_count(const uint8_t* __restrict__ comp,
                                                        const unsigned long long* __restrict__ d_comp_off,
                                                        const uint32_t* __restrict__ d_comp_size,
+                                                       const uint32_t* __restrict__ d_orig_size,
                                                        const uint8_t* __restrict__ d_len, const uint8_t* __restrict__ d_cls,
                                                        const SplitDesc* __restrict__ sdp) {
     constexpr int TBJ = DCZ_SP_TBJ;
@@ -130,8 +131,24 @@ __global__ __launch_bounds__(SP_W) void k4_split_count(const uint8_t* __restrict
         for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
         if (kraft > (1ull << 32) || mx == 0) L.bad_table = 1;
+#if DCZ_K4_MEDIUM_DFA
+        // blocks the nibble automaton takes are counted by its own counting pass (k4_dfa.hip, MODE 2: same test)
+        {
+            const uint32_t orig_blk = d_orig_size[b];
+            const bool long_codes = (unsigned long long)csize * 16ull >= (unsigned long long)orig_blk * 13ull;
+            const bool medium = (unsigned long long)orig_blk * (unsigned long long)DCZ_K4_CLS2_A <=
+                                (unsigned long long)csize * (unsigned long long)DCZ_K4_CLS2_B;
+            uint32_t ni = 0, states = 0;
+            for (int l = 31; l >= 0; l--) {
+                ni = (L.cnt[l + 1] + ni + 1u) / 2u;
+                states += ni;
+            }
+            L.anybad = (!L.bad_table && !long_codes && medium && L.cnt[1] == 0u && states <= 255u) ? 2u : 0u;
+        }
+#endif
     }
     __syncthreads();
+    if (L.anybad == 2u) return;  // workgroup-uniform
     uint32_t* const o_entry = sd.entry + (uint64_t)b * sd.rmax + r;
     uint32_t* const o_count = sd.count + (uint64_t)b * sd.rmax + r;
     uint32_t* const o_exit = sd.exit + (uint64_t)b * sd.rmax + r;
@@ -418,7 +435,10 @@ void launch_split_count(const uint8_t* d_comp, const uint64_t* d_comp_off, const
     hipLaunchKernelGGL(k4_split_setup, dim3(1), dim3(1), 0, s, d_sd, sd, d_comp,
                        reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_cls, K);
     hipLaunchKernelGGL(k4_split_count, dim3(SPLIT_GRID), dim3(SP_W), 0, s, d_comp,
-                       reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_len, d_cls, d_sd);
+                       reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size, d_len, d_cls, d_sd);
+#if DCZ_K4_MEDIUM_DFA
+    launch_count_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, d_cls, d_sd, s);
+#endif
     hipLaunchKernelGGL(k4_split_scan, dim3(K), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_comp_off),
                        d_comp_size, d_orig_size, d_comp, d_cls, d_status, reinterpret_cast<long long*>(d_errpos), d_sd);
 }
