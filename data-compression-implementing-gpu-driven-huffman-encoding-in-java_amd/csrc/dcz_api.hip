@@ -379,7 +379,11 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
         launch_encode(in + ob, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u, c->code + (size_t)k0 * 256u,
                       c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st);
     };
-    if (c->pipeline && g.K >= 2048) {
+    static const uint32_t pipeline_min_k = [] {
+        const char* e = getenv("DCZ_PIPELINE_MIN_K");  // tuning knob
+        return e ? (uint32_t)atoi(e) : 2048u;
+    }();
+    if (c->pipeline && g.K >= pipeline_min_k) {
         const uint32_t ka = g.K / 2, kb = g.K - ka;
         hipStream_t a = c->aux;
         HIPCHK(c, hipEventRecord(c->ev[0], s));  // the aux stream must not run ahead of the caller's earlier work
