@@ -1327,3 +1327,33 @@ def test_sparse_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape,
         probs = np.array([0.6, 0.2, 0.1, 0.1])
     K, nsym = (800, 60000) if shape == "many_blocks" else (12, 700000)
     _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym)
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_fuzz_decode_random_tables(pkg, svc, orc, seed):
+    """Random length tables (Huffman codes of random histograms, complete or made incomplete by lengthening codewords) and
+    data of matching statistics, decoded through the batched entry point with damaged, cut and over-asked blocks mixed in:
+    whichever kernel the classification hands a block to, status, error position and bytes are the oracle's."""
+    rng = np.random.default_rng(7000 + seed)
+    nsyms = int(rng.choice([2, 3, 5, 9, 17, 40, 100, 200, 256]))
+    syms = np.sort(rng.choice(256, size=nsyms, replace=False))
+    shape = rng.choice(["flat", "geometric", "one_dominant", "two_level"])
+    if shape == "flat":
+        p = rng.random(nsyms) + 0.2
+    elif shape == "geometric":
+        p = float(rng.uniform(0.55, 0.97)) ** np.arange(nsyms)
+    elif shape == "one_dominant":
+        p = np.full(nsyms, (1.0 - float(rng.uniform(0.5, 0.995))) / max(1, nsyms - 1))
+        p[0] = 1.0 - p[1:].sum() if nsyms > 1 else 1.0
+    else:
+        p = np.r_[np.full(nsyms // 2 + 1, 1.0), np.full(nsyms - nsyms // 2 - 1, float(rng.uniform(1e-4, 0.1)))][:nsyms]
+    p = p / p.sum()
+    freq = np.zeros(256, np.int64)
+    freq[syms] = np.maximum(1, (p * 1e6).astype(np.int64))
+    lens = np.asarray(orc.build_canonical_codes(freq)[0], np.int32).copy()
+    if seed % 3 == 1:  # incomplete: Kraft sum < 1
+        for s_ in rng.choice(syms, size=max(1, nsyms // 4), replace=False):
+            if lens[s_] < 30:
+                lens[s_] += int(rng.integers(1, 3))
+    K, nsym = (24, 60000) if seed % 2 else (300, 6000)
+    _decode_table_case(pkg, svc, orc, rng, lens, syms, p, K, nsym)
