@@ -36,6 +36,21 @@ struct dcz_ctx {
     uint8_t* st_meta = nullptr;  // 8 KiB of small per-block device fields
     uint8_t* st_batch = nullptr;  // per-chunk device columns of the host-pointer batch API (grow-only)
     size_t st_batch_K = 0;
+    // launch-shape hints (ShapeHint, dcz_internal.h): host-mapped words [0] decode, [1] encode = sequence number of the
+    // last call whose classification met a block for k4_fixed / k3_copy_identity; read without synchronising
+    volatile uint32_t* hint_host = nullptr;
+    uint32_t* hint_dev = nullptr;
+    uint32_t epoch[2] = {0, 0};
+    ShapeHint next_hint(int which) {
+        ShapeHint h;
+        if (!hint_host) return h;  // (no mapped memory: always the flat grids)
+        h.dev = hint_dev + which;
+        h.epoch = ++epoch[which];
+        const uint32_t seen = hint_host[which];
+        // unknown on the first call; afterwards "likely" while a call of the last 8 had such a block
+        h.likely = h.epoch <= 1u || (seen != 0u && seen + 8u >= h.epoch);
+        return h;
+    }
     void* pinned[2] = {nullptr, nullptr};  // pinned host staging handed out by dcz_ctx_pinned (grow-only)
     size_t pinned_cap[2] = {0, 0};
     // profiling
@@ -257,6 +272,20 @@ int dcz_ctx_create(int device, dcz_ctx** out) {
               hipMalloc(reinterpret_cast<void**>(&c->st_meta), 8192) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->carry), 64) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    {
+        void* hp = nullptr;
+        const char* nh = std::getenv("DCZ_NO_SHAPE_HINT");
+        if (!(nh && nh[0] && nh[0] != '0') && hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+            std::memset(hp, 0, 64);
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                c->hint_host = static_cast<volatile uint32_t*>(hp);
+                c->hint_dev = static_cast<uint32_t*>(dp);
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+    }
     if (const char* np = std::getenv("DCZ_NO_PIPELINE")) c->pipeline = !(np[0] && np[0] != '0');
     if (!ok) {
         dcz_ctx_destroy(c);
@@ -287,6 +316,7 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     (void)hipFree(c->st_batch);
     for (auto p : c->pinned)
         if (p) (void)hipHostFree(p);
+    if (c->hint_host) (void)hipHostFree(const_cast<uint32_t*>(c->hint_host));
     (void)hipFree(c->carry);
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -358,6 +388,7 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
         KernelTimer t(c, st, DCZ_K_HISTOGRAM);
         launch_histogram(in + ob, lb, block_bytes, g.spb, (uint64_t)kn * g.spb, c->seg_hist + s0 * 256u, st);
     };
+    const ShapeHint enc_hint = c->next_hint(1);
     auto k2 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
         size_t ob, lb;
         uint64_t s0;
@@ -365,7 +396,7 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
         KernelTimer t(c, st, DCZ_K_CODEBUILD);
         launch_codebuild(c->seg_hist + s0 * 256u, nullptr, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u,
                          c->code + (size_t)k0 * 256u, c->maxlen + k0, d_comp_size + k0, c->seg_bitoff + s0,
-                         d_status + k0, st);
+                         d_status + k0, st, enc_hint);
     };
     auto k3 = [&](uint32_t k0, uint32_t kn, const uint64_t* carry_in, uint64_t* total_out, hipStream_t st) {
         size_t ob, lb;
@@ -377,7 +408,7 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
         }
         KernelTimer t(c, st, DCZ_K_ENCODE);
         launch_encode(in + ob, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u, c->code + (size_t)k0 * 256u,
-                      c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st);
+                      c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st, enc_hint);
     };
     static const uint32_t pipeline_min_k = [] {
         const char* e = getenv("DCZ_PIPELINE_MIN_K");  // tuning knob
@@ -423,9 +454,10 @@ int dcz_decompress_blocks(dcz_ctx* c, const void* d_comp, size_t comp_bytes, con
     if (r != DCZ_OK) return r;
     {
         KernelTimer t(c, s, DCZ_K_DECODE);
+        DecodeWs ws = decode_ws_at(c->dws, c->cap_dws_K);
+        ws.fixed = c->next_hint(0);
         launch_decode(static_cast<const uint8_t*>(d_comp), comp_bytes, d_comp_off, d_comp_size, d_orig_size, d_len,
-                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos,
-                      decode_ws_at(c->dws, c->cap_dws_K), s);
+                      (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, ws, s);
     }
     return launch_check(c);
 }

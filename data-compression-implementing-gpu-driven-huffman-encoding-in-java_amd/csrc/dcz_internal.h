@@ -19,10 +19,25 @@ void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_
 // Histogram of a byte window into 256 x i64 (single-block API; sums the segment rows on the device).
 void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s);
 
+// Launch-shape hint.  Two kernels serve blocks that most inputs do not have (k4_fixed: fixed-length complete codes,
+// k3_copy_identity: 256 symbols of 8 bits) with a flat grid of one workgroup per 16 KiB tile of EVERY block, because that
+// is what copies fastest; on inputs without such blocks those grids cost 0.06-0.11 ms per 8 GiB for nothing.  The
+// classification (k4_classify, k2_codebuild) stores the call's sequence number into a host-mapped word whenever it meets
+// such a block; the host reads the word -- without synchronising, so it reflects calls that have completed -- and gives
+// the kernels a small persistent grid instead when none was seen in the last calls.  Both shapes are correct for any
+// input; the hint only chooses the cheaper one.
+struct ShapeHint {
+    uint32_t* dev = nullptr;  // device address of the word (nullptr: nothing is recorded)
+    uint32_t epoch = 0;       // this call's sequence number (> 0)
+    bool likely = true;       // flat grid
+};
+constexpr uint32_t HINT_PERSIST_GRID = 1024;
+
 // K2: per-block code build + per-segment bit offsets.
 void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t n, size_t block_bytes,
                       uint32_t segs_per_block, uint32_t K, uint8_t* d_len, uint32_t* d_code, uint8_t* d_maxlen,
-                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s);
+                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s,
+                      const ShapeHint& hint = ShapeHint());
 // Canonical codes from stored lengths (CH.generateCanonicalCodesFromLengths), one block per workgroup.
 void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s);
 // Exclusive scan of comp_size -> comp_off, total, capacity check.
@@ -33,7 +48,8 @@ void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_of
 // K3: encode.
 void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,
                    const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
-                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s);
+                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s,
+                   const ShapeHint& hint = ShapeHint());
 
 // K4: decode.  Region table of the split decoder (k4_split.hip): a block cut into regions of region_bytes of payload,
 // one workgroup per region; the arrays are [block][rmax].
@@ -87,6 +103,7 @@ struct DecodeWs {
     uint8_t* cls;        // K x u8: class byte of every block (k4_classify, then the probe launch / k4_split_scan)
     SplitDesc* sdesc;    // device copy of the region table descriptor of this call
     uint32_t* split;     // 4 x SPLIT_ENTRIES + SPLIT_MAX_BLOCKS + (SPLIT_MAX_BLOCKS + 1) u32
+    ShapeHint fixed;     // launch shape of k4_fixed (set by the caller of launch_decode)
 };
 inline size_t decode_ws_bytes(size_t K) {
     return ((K + 255) & ~(size_t)255) + 256 + (4 * SPLIT_ENTRIES + 2 * SPLIT_MAX_BLOCKS + 4) * 4;
@@ -94,7 +111,7 @@ inline size_t decode_ws_bytes(size_t K) {
 inline DecodeWs decode_ws_at(void* base, size_t K) {
     uint8_t* p = static_cast<uint8_t*>(base);
     const size_t kb = (K + 255) & ~(size_t)255;
-    return DecodeWs{p, reinterpret_cast<SplitDesc*>(p + kb), reinterpret_cast<uint32_t*>(p + kb + 256)};
+    return DecodeWs{p, reinterpret_cast<SplitDesc*>(p + kb), reinterpret_cast<uint32_t*>(p + kb + 256), ShapeHint()};
 }
 void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                    const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
                                                      uint8_t* __restrict__ d_len, uint32_t* __restrict__ d_code,
                                                      uint8_t* __restrict__ d_maxlen, uint32_t* __restrict__ d_comp_size,
                                                      unsigned long long* __restrict__ d_seg_bitoff,
-                                                     int32_t* __restrict__ d_status) {
+                                                     int32_t* __restrict__ d_status, uint32_t* __restrict__ hint,
+                                                     uint32_t epoch) {
     __shared__ CodeLds L;
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
     bits = wave_reduce_add_u64(bits);
     if (tid == 0) {
         // bit 7: 256 symbols of 8 bits, i.e. codeword(s) = s and the payload is a copy of the input (K3 copies it)
-        d_maxlen[b] = (uint8_t)(too_long ? 0 : (maxlen | ((maxlen == 8 && L.nsym == 256) ? 0x80 : 0)));
+        const bool identity = !too_long && maxlen == 8 && L.nsym == 256;
+        d_maxlen[b] = (uint8_t)(too_long ? 0 : (maxlen | (identity ? 0x80 : 0)));
+        if (identity && hint) *hint = epoch;  // (ShapeHint: k3_copy_identity has work in calls like this one)
         d_comp_size[b] = too_long ? 0u : (uint32_t)((bits + 7) >> 3);
         d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
     }
@@ -365,11 +368,12 @@ __global__ __launch_bounds__(1024) void k2_offsets(const uint32_t* __restrict__ 
 
 void launch_codebuild(const uint16_t* seg_hist, const int64_t* d_hist_in, size_t n, size_t block_bytes,
                       uint32_t segs_per_block, uint32_t K, uint8_t* d_len, uint32_t* d_code, uint8_t* d_maxlen,
-                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s) {
+                      uint32_t* d_comp_size, uint64_t* d_seg_bitoff, int32_t* d_status, hipStream_t s,
+                      const ShapeHint& hint) {
     if (K == 0) return;
     hipLaunchKernelGGL(k2_codebuild, dim3(K), dim3(K2_T), 0, s, seg_hist, reinterpret_cast<const long long*>(d_hist_in),
                        n, block_bytes, segs_per_block, K, d_len, d_code, d_maxlen, d_comp_size,
-                       reinterpret_cast<unsigned long long*>(d_seg_bitoff), d_status);
+                       reinterpret_cast<unsigned long long*>(d_seg_bitoff), d_status, hint.dev, hint.epoch);
 }
 
 void launch_codes_from_lengths(const int32_t* d_len32, uint32_t* d_code, int32_t* d_status, hipStream_t s) {

@@ -401,14 +401,21 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
 // itself -- the reference's high-entropy case (app/logs/datacomp.log:3254).  A flat grid of one workgroup per (block,
 // 16 KiB tile) over all blocks copies them with non-temporal 16 B/lane accesses (see k4_fixed.hip for why flat); a
 // workgroup of any other block leaves after one byte load, and k3_encode leaves at once for the blocks handled here.
-constexpr uint32_t CP_TILE = 16384;
-__global__ __launch_bounds__(256) void k3_copy_identity(const uint8_t* __restrict__ in, size_t n, size_t block_bytes,
-                                                        uint32_t tiles_per_block, uint32_t b0,
-                                                        const uint8_t* __restrict__ d_maxlen,
-                                                        const unsigned long long* __restrict__ d_comp_off,
-                                                        const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
-    const uint32_t bq = blockIdx.x / tiles_per_block;
-    const uint32_t tile = blockIdx.x - bq * tiles_per_block;
+#ifndef DCZ_CP_TILE
+#define DCZ_CP_TILE 16384
+#endif
+constexpr uint32_t CP_TILE = DCZ_CP_TILE;
+#ifndef DCZ_CP_T
+#define DCZ_CP_T 256  // threads per tile, four 16-byte accesses per lane (see k4_fixed.hip for the shapes measured)
+#endif
+constexpr int CP_T = DCZ_CP_T;
+constexpr int CP_UPT = (int)(CP_TILE / 16u / (uint32_t)CP_T);
+static_assert(CP_UPT >= 1 && CP_UPT * CP_T * 16 == (int)CP_TILE, "tile = threads x units x 16 bytes");
+// one work item: tile `tile` of block b0 + bq
+__device__ __forceinline__ void copy_identity_item(uint32_t bq, uint32_t tile, const uint8_t* __restrict__ in, size_t n,
+                                                   size_t block_bytes, uint32_t b0, const uint8_t* __restrict__ d_maxlen,
+                                                   const unsigned long long* __restrict__ d_comp_off,
+                                                   const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
     const uint32_t b = b0 + bq;
     if ((d_maxlen[b] & 0x80u) == 0u || d_status[b] != DCZ_OK) return;  // workgroup-uniform
     const uint64_t bstart = (uint64_t)b * block_bytes;
@@ -422,33 +429,68 @@ __global__ __launch_bounds__(256) void k3_copy_identity(const uint8_t* __restric
     if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0u && nout == CP_TILE) {
         const u32x4* s4 = reinterpret_cast<const u32x4*>(src) + tid;
         u32x4* d4 = reinterpret_cast<u32x4*>(dst) + tid;
-        u32x4 v[4];
+        u32x4 v[CP_UPT];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(s4 + 256 * k);
+        for (int k = 0; k < CP_UPT; k++) v[k] = __builtin_nontemporal_load(s4 + CP_T * k);
 #pragma unroll
-        for (int k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], d4 + 256 * k);
+        for (int k = 0; k < CP_UPT; k++) __builtin_nontemporal_store(v[k], d4 + CP_T * k);
     } else if (((((uintptr_t)src) | ((uintptr_t)dst)) & 3u) == 0u) {
         const uint32_t nw = nout >> 2;
-        for (uint32_t i = (uint32_t)tid; i < nw; i += 256u)
+        for (uint32_t i = (uint32_t)tid; i < nw; i += (uint32_t)CP_T)
             reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
-        for (uint32_t i = (nw << 2) + (uint32_t)tid; i < nout; i += 256u) dst[i] = src[i];
+        for (uint32_t i = (nw << 2) + (uint32_t)tid; i < nout; i += (uint32_t)CP_T) dst[i] = src[i];
     } else {
-        for (uint32_t i = (uint32_t)tid; i < nout; i += 256u) dst[i] = src[i];
+        for (uint32_t i = (uint32_t)tid; i < nout; i += (uint32_t)CP_T) dst[i] = src[i];
+    }
+}
+
+// PERSIST = false: flat grid, one workgroup per work item (what copies fastest).  PERSIST = true: a small grid that walks
+// over the work items -- for calls in which no block is expected to have the identity code (ShapeHint, dcz_internal.h).
+template <bool PERSIST>
+__global__ __launch_bounds__(CP_T) void k3_copy_identity(const uint8_t* __restrict__ in, size_t n, size_t block_bytes,
+                                                         uint32_t tiles_per_block, uint32_t b0, uint32_t nblk,
+                                                         const uint8_t* __restrict__ d_maxlen,
+                                                         const unsigned long long* __restrict__ d_comp_off,
+                                                         const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
+    if constexpr (!PERSIST) {
+        const uint32_t bq = blockIdx.x / tiles_per_block;
+        copy_identity_item(bq, blockIdx.x - bq * tiles_per_block, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out);
+    } else {
+        // CP_T blocks at a time: all threads look at one flag each, and a range without a flagged block is skipped whole
+        for (uint32_t c0 = 0; c0 < nblk; c0 += (uint32_t)CP_T) {
+            const uint32_t bi = c0 + threadIdx.x;
+            const int mine = bi < nblk && (d_maxlen[b0 + bi] & 0x80u) != 0u;
+            if (!__syncthreads_or(mine)) continue;  // workgroup-uniform
+            const uint32_t c1 = (nblk - c0 < (uint32_t)CP_T) ? nblk : c0 + (uint32_t)CP_T;
+            for (uint32_t bq = c0; bq < c1; bq++) {
+                if ((d_maxlen[b0 + bq] & 0x80u) == 0u) continue;
+                for (uint32_t tile = blockIdx.x; tile < tiles_per_block; tile += gridDim.x)
+                    copy_identity_item(bq, tile, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out);
+            }
+        }
     }
 }
 
 void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint32_t K,
                    const uint8_t* d_len, const uint32_t* d_code, const uint8_t* d_maxlen, const uint64_t* d_comp_off,
-                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s) {
+                   const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s,
+                   const ShapeHint& hint) {
     if (K == 0) return;
-    {
+    if (!hint.likely) {
+        const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;
+        const uint64_t tpb = (eff + CP_TILE - 1) / CP_TILE;
+        if (tpb <= 0xFFFFFFFFull)
+            hipLaunchKernelGGL(k3_copy_identity<true>, dim3(HINT_PERSIST_GRID), dim3(CP_T), 0, s, d_in, n, block_bytes,
+                               (uint32_t)tpb, 0u, K, d_maxlen, reinterpret_cast<const unsigned long long*>(d_comp_off),
+                               d_status, d_out);
+    } else {
         const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;
         const uint64_t tpb = (eff + CP_TILE - 1) / CP_TILE;
         const uint64_t per = (0x40000000ull / tpb) ? (0x40000000ull / tpb) : 1;  // blocks per launch (grid < 2^31)
         for (uint64_t b0 = 0; b0 < K; b0 += per) {
             const uint64_t kb = (K - b0 < per) ? K - b0 : per;
-            hipLaunchKernelGGL(k3_copy_identity, dim3((uint32_t)(kb * tpb)), dim3(256), 0, s, d_in, n, block_bytes,
-                               (uint32_t)tpb, (uint32_t)b0, d_maxlen,
+            hipLaunchKernelGGL(k3_copy_identity<false>, dim3((uint32_t)(kb * tpb)), dim3(CP_T), 0, s, d_in, n, block_bytes,
+                               (uint32_t)tpb, (uint32_t)b0, (uint32_t)kb, d_maxlen,
                                reinterpret_cast<const unsigned long long*>(d_comp_off), d_status, d_out);
         }
     }

@@ -24,15 +24,29 @@
 
 namespace dcz {
 
-constexpr uint32_t FX_TILE = 16384;  // output bytes per work item (256 threads x 4 x 16 B)
-constexpr int FX_T = 256;
+// Work item shape.  One 16-byte access per lane copies fastest in isolation (tools/micro/copybench2.hip, 8 GiB, flat grids,
+// non-temporal: 256 threads x 4 per lane 6.06 TB/s, 1024 x 1 6.39, 512 x 1 6.53, 256 x 1 with 4 KiB tiles 6.60), but it
+// takes four times the waves, and the waves of a launch that finds no fixed-length block cost what they cost: measured in
+// the library, 512 x 1 with 8 KiB tiles gains 0.1 ms per 4 GiB on the identity copy of K3 and nothing here, and adds
+// 0.1-0.15 ms per 4 GiB to every launch on text and low-entropy input.  So: 256 threads, four accesses per lane.
+#ifndef DCZ_FX_TILE
+#define DCZ_FX_TILE 16384
+#endif
+constexpr uint32_t FX_TILE = DCZ_FX_TILE;  // output bytes per work item
+#ifndef DCZ_FX_T
+#define DCZ_FX_T 256
+#endif
+constexpr int FX_T = DCZ_FX_T;
+constexpr int FX_UPT = (int)(FX_TILE / 16u / (uint32_t)FX_T);  // 16-byte units per thread
+static_assert(FX_T >= 256 && FX_UPT * FX_T * 16 == (int)FX_TILE, "tile = threads x units x 16 bytes");
 
 __global__ __launch_bounds__(256) void k4_classify(const uint8_t* __restrict__ d_len,
                                                    const unsigned long long* __restrict__ d_comp_off,
                                                    const uint32_t* __restrict__ d_comp_size,
                                                    const uint32_t* __restrict__ d_orig_size, unsigned long long comp_bytes,
                                                    unsigned long long out_stride, uint32_t K, uint8_t* __restrict__ cls,
-                                                   int32_t* __restrict__ d_status, long long* __restrict__ d_errpos) {
+                                                   int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
+                                                   uint32_t* __restrict__ hint, uint32_t epoch) {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= K) return;
     const uint4* row = reinterpret_cast<const uint4*>(d_len + (uint64_t)b * 256u);
@@ -63,6 +77,7 @@ __global__ __launch_bounds__(256) void k4_classify(const uint8_t* __restrict__ d
         if (d_errpos) d_errpos[b] = 0;
     }
     cls[b] = c;
+    if ((c & 0xF0u) == 0x10u && hint) *hint = epoch;  // (ShapeHint: k4_fixed has work in calls like this one)
 }
 
 // 16 bytes at virtual byte offset vb0 (any alignment) of the payload whose 16-byte aligned base is vbase; bytes outside
@@ -101,19 +116,22 @@ __device__ __forceinline__ uint4 extract16(const uint32_t (&bw)[5], const uint8_
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-__global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ comp,
-                                                 const unsigned long long* __restrict__ d_comp_off,
-                                                 const uint32_t* __restrict__ d_comp_size,
-                                                 const uint32_t* __restrict__ d_orig_size,
-                                                 const uint8_t* __restrict__ d_len, unsigned long long out_stride,
-                                                 uint8_t* __restrict__ out, const uint8_t* __restrict__ cls,
-                                                 uint32_t tiles_per_block, uint32_t wg0) {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[(FX_TILE / 8 * 7 + 64) / 4];  // payload of one tile, L <= 7
-    __shared__ uint8_t symtab[256];
-    __shared__ uint32_t wcnt[FX_T / 64];
-    const uint32_t wi = wg0 + blockIdx.x;
-    const uint32_t b = wi / tiles_per_block;
-    const uint32_t tile = wi - b * tiles_per_block;
+struct FxLds {
+    __attribute__((aligned(16))) uint32_t stage[(FX_TILE / 8 * 7 + 64) / 4];  // payload of one tile, L <= 7
+    uint8_t symtab[256];
+    uint32_t wcnt[FX_T / 64];
+};
+
+// one work item: tile `tile` of block b
+__device__ __forceinline__ void fixed_item(FxLds& S, uint32_t b, uint32_t tile, const uint8_t* __restrict__ comp,
+                                           const unsigned long long* __restrict__ d_comp_off,
+                                           const uint32_t* __restrict__ d_comp_size,
+                                           const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
+                                           unsigned long long out_stride, uint8_t* __restrict__ out,
+                                           const uint8_t* __restrict__ cls) {
+    uint32_t* const stage = S.stage;
+    uint8_t* const symtab = S.symtab;
+    uint32_t* const wcnt = S.wcnt;
     const uint32_t c = cls[b];
     if ((c & 0xF0u) != 0x10u) return;  // workgroup-uniform: not a fixed-length block
     const uint32_t L = c & 15u;
@@ -133,18 +151,18 @@ __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ com
         if (skew == 0u && dst_al && nout == FX_TILE && t0 + FX_TILE <= vhi) {  // interior tile: a plain streaming copy
             const u32x4* s4 = reinterpret_cast<const u32x4*>(vbase + t0) + tid;
             u32x4* d4 = reinterpret_cast<u32x4*>(dst0) + tid;
-            u32x4 v[4];
+            u32x4 v[FX_UPT];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(s4 + 256 * k);
+            for (int k = 0; k < FX_UPT; k++) v[k] = __builtin_nontemporal_load(s4 + FX_T * k);
 #pragma unroll
-            for (int k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], d4 + 256 * k);
+            for (int k = 0; k < FX_UPT; k++) __builtin_nontemporal_store(v[k], d4 + FX_T * k);
             return;
         }
-        uint4 v[4];
+        uint4 v[FX_UPT];
         const uint32_t q = skew >> 2, r = skew & 3u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t o = ((uint32_t)tid + 256u * k) * 16u;
+        for (int k = 0; k < FX_UPT; k++) {
+            const uint32_t o = ((uint32_t)tid + (uint32_t)FX_T * k) * 16u;
             v[k] = make_uint4(0, 0, 0, 0);
             if (o < nout) {
                 const uint4 a = load_chunk16(vbase, t0 + o, vlo, vhi);  // aligned chunk holding the unit's first byte
@@ -158,20 +176,20 @@ __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ com
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t o = ((uint32_t)tid + 256u * k) * 16u;
+        for (int k = 0; k < FX_UPT; k++) {
+            const uint32_t o = ((uint32_t)tid + (uint32_t)FX_T * k) * 16u;
             if (o < nout) store_unit(dst0 + o, v[k], nout - o, dst_al);
         }
         return;
     }
     // ---- L < 8: the present symbols in ascending order ----
     {
-        const bool present = d_len[(uint64_t)b * 256u + tid] != 0;
+        const bool present = tid < 256 && d_len[(uint64_t)b * 256u + (tid & 255)] != 0;  // (thread = symbol)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(present);
-        if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__builtin_popcountll(m);
+        if (tid < 256 && (tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__builtin_popcountll(m);
         __syncthreads();
         uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
-        for (int w = 0; w < (tid >> 6); w++) rank += wcnt[w];
+        for (int w = 0; w < ((tid & 255) >> 6); w++) rank += wcnt[w];
         if (present) symtab[rank] = (uint8_t)tid;
     }
     // payload bytes of this tile: virtual [skew + t0 * L / 8, + nout * L / 8 rounded up); t0 * L / 8 is a multiple of 16
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ com
         reinterpret_cast<uint4*>(stage)[ch] = load_chunk16(vbase, vin + 16ull * ch, vlo, vhi);
     __syncthreads();
 #pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-        const uint32_t u = (uint32_t)tid + 256u * k;  // unit of 16 symbols inside the tile
+    for (int k = 0; k < FX_UPT; k++) {
+        const uint32_t u = (uint32_t)tid + (uint32_t)FX_T * k;  // unit of 16 symbols inside the tile
         const uint32_t o = u * 16u;
         if (o >= nout) break;
         const uint32_t off = skew + 2u * L * u;  // byte of the unit's first bit inside the stage
@@ -210,13 +228,47 @@ __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ com
     }
 }
 
+// PERSIST = false: flat grid, one workgroup per work item (what copies fastest).  PERSIST = true: a small grid that walks
+// over the work items -- for calls in which no fixed-length block is expected (ShapeHint, dcz_internal.h).
+template <bool PERSIST>
+__global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ comp,
+                                                 const unsigned long long* __restrict__ d_comp_off,
+                                                 const uint32_t* __restrict__ d_comp_size,
+                                                 const uint32_t* __restrict__ d_orig_size,
+                                                 const uint8_t* __restrict__ d_len, unsigned long long out_stride,
+                                                 uint8_t* __restrict__ out, const uint8_t* __restrict__ cls,
+                                                 uint32_t tiles_per_block, uint32_t wg0, uint32_t nblk) {
+    __shared__ FxLds S;
+    if constexpr (!PERSIST) {
+        const uint32_t wi = wg0 + blockIdx.x;
+        const uint32_t b = wi / tiles_per_block;
+        fixed_item(S, b, wi - b * tiles_per_block, comp, d_comp_off, d_comp_size, d_orig_size, d_len, out_stride, out, cls);
+    } else {
+        // FX_T blocks at a time: all threads look at one class byte each, and a range without a fixed-length block is
+        // skipped whole
+        for (uint32_t c0 = 0; c0 < nblk; c0 += (uint32_t)FX_T) {
+            const uint32_t bi = c0 + threadIdx.x;
+            const int mine = bi < nblk && (cls[bi] & 0xF0u) == 0x10u;
+            if (!__syncthreads_or(mine)) continue;  // workgroup-uniform
+            const uint32_t c1 = (nblk - c0 < (uint32_t)FX_T) ? nblk : c0 + (uint32_t)FX_T;
+            for (uint32_t b = c0; b < c1; b++) {
+                if ((cls[b] & 0xF0u) != 0x10u) continue;
+                for (uint32_t tile = blockIdx.x; tile < tiles_per_block; tile += gridDim.x) {
+                    fixed_item(S, b, tile, comp, d_comp_off, d_comp_size, d_orig_size, d_len, out_stride, out, cls);
+                    __syncthreads();  // (the staging area and the symbol table are reused)
+                }
+            }
+        }
+    }
+}
+
 void launch_classify(const uint8_t* d_len, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                      const uint32_t* d_orig_size, size_t comp_bytes, size_t out_stride, uint32_t K, const DecodeWs& ws,
                      int32_t* d_status, int64_t* d_errpos, hipStream_t s) {
     hipLaunchKernelGGL(k4_classify, dim3((K + 255) / 256), dim3(256), 0, s, d_len,
                        reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size,
                        (unsigned long long)comp_bytes, (unsigned long long)out_stride, K, ws.cls, d_status,
-                       reinterpret_cast<long long*>(d_errpos));
+                       reinterpret_cast<long long*>(d_errpos), ws.fixed.dev, ws.fixed.epoch);
 }
 
 void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
@@ -224,14 +276,20 @@ void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
                          const DecodeWs& ws, hipStream_t s) {
     const unsigned long long tpb = ((unsigned long long)out_stride + FX_TILE - 1) / FX_TILE;
     if (tpb == 0 || tpb > 0x7FFFFFFFull) return;
+    if (!ws.fixed.likely) {  // no fixed-length block in the last calls: a small grid that finds out for itself
+        hipLaunchKernelGGL(k4_fixed<true>, dim3(HINT_PERSIST_GRID), dim3(FX_T), 0, s, d_comp,
+                           reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size, d_len,
+                           (unsigned long long)out_stride, d_out, ws.cls, (uint32_t)tpb, 0u, K);
+        return;
+    }
     const unsigned long long items = (unsigned long long)K * tpb;  // < 2^62; launched in slices of < 2^31 workgroups
     const unsigned long long slice = (0x40000000ull / tpb) * tpb ? (0x40000000ull / tpb) * tpb : tpb;
     for (unsigned long long w0 = 0; w0 < items; w0 += slice) {
         const unsigned long long cnt = (items - w0 < slice) ? items - w0 : slice;
         if (w0 > 0xFFFFFFFFull) break;  // (K < 2^31 blocks of >= 1 tile: unreachable for buffers that exist)
-        hipLaunchKernelGGL(k4_fixed, dim3((uint32_t)cnt), dim3(FX_T), 0, s, d_comp,
+        hipLaunchKernelGGL(k4_fixed<false>, dim3((uint32_t)cnt), dim3(FX_T), 0, s, d_comp,
                            reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size, d_len,
-                           (unsigned long long)out_stride, d_out, ws.cls, (uint32_t)tpb, (uint32_t)w0);
+                           (unsigned long long)out_stride, d_out, ws.cls, (uint32_t)tpb, (uint32_t)w0, K);
     }
 }
 

@@ -1357,3 +1357,18 @@ def test_fuzz_decode_random_tables(pkg, svc, orc, seed):
                 lens[s_] += int(rng.integers(1, 3))
     K, nsym = (24, 60000) if seed % 2 else (300, 6000)
     _decode_table_case(pkg, svc, orc, rng, lens, syms, p, K, nsym)
+
+
+def test_launch_shape_hint_both_shapes_on_both_kinds_of_input(pkg, orc):
+    """k4_fixed and k3_copy_identity get a flat grid when a recent call met a block for them and a small persistent grid
+    otherwise (ShapeHint); either shape must handle either kind of input, whatever the calls before were."""
+    torch = _torch()
+    svc = pkg.HipCompressionService(1, 0)  # a context of its own: the hint is per context
+    text = orc.gen_text(5, 0, 6 * 65536 + 100)
+    rnd = orc.java_random_bytes(77, 40 * 65536 + 4321)   # 256 symbols of 8 bits in every full block: identity / fixed
+    six = np.random.default_rng(5).integers(0, 64, size=9 * 65536 + 17).astype(np.uint8) + 32  # fixed-length, 6 bits
+    seq = [text] * 2 + [rnd] * 3 + [text] * 10 + [rnd, six, rnd] + [text] * 10 + [six] * 2
+    for i, data in enumerate(seq):
+        assert_parity(svc, orc, data, 65536)
+        if i % 4 == 3:
+            torch.cuda.synchronize()  # (let some hints arrive, leave others in flight)
