@@ -537,32 +537,59 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             __threadfence_block();
             __syncthreads();
             const bool mine = nsym > 0u && o < lim;
+            // Only the subsequence that straddles lim (the end of the block) needs its stores checked: waves without it
+            // take a walk whose store block is as small as it gets -- the store executes whenever ANY lane of the wave has
+            // a symbol other than z in the step (9 steps of 10 on 1 % noise), so its instructions count for all lanes.
+            const bool inside = o + nsym <= lim;
             if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
                 uint32_t e = g << 6;
                 DFA_FRESH(R);
                 uint32_t t = o;
                 const uint32_t cmask = mine ? 7u : 0u, zmask = mine ? 0x18u : 0u;  // switched-off lanes store nothing
-                auto stepS = [&](auto jc) __attribute__((always_inline)) {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int sh = 26 - 4 * (j & 7);
-                    if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                    const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                    e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
-                    const uint32_t nz = e & zmask;
-                    if (nz != 0u) {  // (one lane in 25 on 1 % noise; the last subsequence of a block may run past lim)
-                        const uint32_t tp = t + ((e >> 14) & 3u);
-                        if (nz == 0x08u) {
-                            if (tp < lim) dst[tp] = (uint8_t)(e >> 16);
-                        } else {
-                            if (t < lim) dst[t] = (uint8_t)(e >> 16);
-                            if (tp < lim) dst[tp] = (uint8_t)(e >> 24);
+                if (__builtin_amdgcn_ballot_w64(mine && !inside) == 0ull) {  // wave-uniform
+                    auto stepF = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sh = 26 - 4 * (j & 7);
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
+                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
+                        const uint32_t nz = e & zmask;
+                        if (nz != 0u) {
+                            const uint32_t tp = t + ((e >> 14) & 3u);
+                            const bool two = nz == 0x10u;  // (1 step in 10^4: sym0 at t, sym1 at tp)
+                            dst[two ? t : tp] = (uint8_t)(e >> 16);
+                            if (__builtin_amdgcn_ballot_w64(two) != 0ull) {
+                                if (two) dst[tp] = (uint8_t)(e >> 24);
+                            }
                         }
-                    }
-                    t += e & cmask;
-                };
-                [&]<int... Js>(std::integer_sequence<int, Js...>) {
-                    (stepS(std::integral_constant<int, Js>{}), ...);
-                }(std::make_integer_sequence<int, 64>{});
+                        t += e & cmask;
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepF(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64>{});
+                } else {
+                    auto stepS = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sh = 26 - 4 * (j & 7);
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
+                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
+                        const uint32_t nz = e & zmask;
+                        if (nz != 0u) {
+                            const uint32_t tp = t + ((e >> 14) & 3u);
+                            if (nz == 0x08u) {
+                                if (tp < lim) dst[tp] = (uint8_t)(e >> 16);
+                            } else {
+                                if (t < lim) dst[t] = (uint8_t)(e >> 16);
+                                if (tp < lim) dst[tp] = (uint8_t)(e >> 24);
+                            }
+                        }
+                        t += e & cmask;
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepS(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64>{});
+                }
             }
             (void)more;
         } else {
