@@ -55,6 +55,11 @@ namespace dcz {
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
+#ifndef DCZ_DFA_SPARSE_WAVEFILL
+#define DCZ_DFA_SPARSE_WAVEFILL 0  // SPARSE, 1: every wave fills its own output range, no fence (bit-exact in every test, but it
+                                   // leans on one wave's stores reaching memory in order across lanes, and measures the
+                                   // same: 3.12 vs 3.02 ms -- the kernel is bound by its write traffic, not by the wait)
+#endif
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output): 1 = phase B stores all go to the dummy bytes, 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
@@ -519,6 +524,31 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         if constexpr (SPARSE) {
             // ---- phase B, sparse: fill the window's output with z, then the same walk stores the other symbols ----
             uint8_t* const dst = oblk + produced;  // lim bytes
+#if DCZ_DFA_SPARSE_WAVEFILL
+            // Every WAVE fills exactly the bytes its own lanes own -- [o of its lane 0, o + nsym of its lane 63), clipped to
+            // lim; the ranges of consecutive waves abut -- and then walks.  A byte is only ever stored by the wave that
+            // filled it, later in that wave's program order, and one wave's stores reach memory in order: no fence, no
+            // barrier, and the fill drains while the wave walks.
+            {
+                const uint32_t z = L.symtab[0];
+                const int lane = tid & 63;
+                uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+                uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)(o + nsym), 63);
+                if (ws > lim) ws = lim;
+                if (we > lim) we = lim;
+                uint8_t* const fd = dst + ws;
+                const uint32_t len = we - ws;
+                uint32_t head = (16u - (uint32_t)((uintptr_t)fd & 15u)) & 15u;
+                if (head > len) head = len;
+                if ((uint32_t)lane < head) fd[lane] = (uint8_t)z;
+                const uint32_t body = (len - head) >> 4;
+                const uint32_t z4 = z * 0x01010101u;
+                uint4* const d4 = reinterpret_cast<uint4*>(fd + head);
+                for (uint32_t u = (uint32_t)lane; u < body; u += 64u) d4[u] = make_uint4(z4, z4, z4, z4);
+                const uint32_t t0 = head + (body << 4);
+                if ((uint32_t)lane < len - t0) fd[t0 + lane] = (uint8_t)z;
+            }
+#else
             {
                 const uint32_t z = L.symtab[0];
                 uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
@@ -536,6 +566,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             // scope fence here costs 8x the whole kernel, see k4_decode.hip).
             __threadfence_block();
             __syncthreads();
+#endif
             const bool mine = nsym > 0u && o < lim;
             // Only the subsequence that straddles lim (the end of the block) needs its stores checked: waves without it
             // take a walk whose store block is as small as it gets -- the store executes whenever ANY lane of the wave has
