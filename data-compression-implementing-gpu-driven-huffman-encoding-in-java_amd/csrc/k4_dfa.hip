@@ -55,6 +55,9 @@ namespace dcz {
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
+#ifndef DCZ_DFA_SPARSE_OC
+#define DCZ_DFA_SPARSE_OC 0  // SPARSE has no tile; a non-zero value only reserves LDS, i.e. limits the workgroups per CU
+#endif
 #ifndef DCZ_DFA_SPARSE_WAVEFILL
 #define DCZ_DFA_SPARSE_WAVEFILL 0  // SPARSE, 1: every wave fills its own output range, no fence (bit-exact in every test, but it
                                    // leans on one wave's stores reaching memory in order across lanes, and measures the
@@ -809,7 +812,7 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
         hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, 0, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, 0, 0, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_SPARSE_OC, 0, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #endif
     } else {  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
