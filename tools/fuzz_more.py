@@ -5,7 +5,8 @@ pkg = g.load_package(); orc = g.load_oracle()
 import test_gpu_parity as T
 svc = pkg.HipCompressionService(1, 0)
 bad = 0
-for seed in range(5000, 8000):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5000, 8000)
+for seed in range(lo, hi):
     data, bb = T._fuzz_case(seed)
     try:
         T.assert_parity(svc, orc, data, bb)
