@@ -7,7 +7,7 @@
 // (profiles/r02_base_text8g_sq.txt): the kernel is INSTRUCTION-ISSUE bound -- per 64 symbols 33 vector + 14 scalar + 6 LDS
 // instructions, the vector pipe of a SIMD ~60 % busy with four waves -- and a wave runs as long as its slowest lane
 // (70 steps for 52 symbols on average).  This kernel does the same work with fewer, branch-free instructions:
-//   * the decoder is a finite automaton over NIBBLES: state = internal node of the code tree (<= 254 states, root = 0),
+//   * the decoder is a finite automaton over NIBBLES: state = internal node of the code tree (<= 255 states, root = 0),
 //     T[state][nibble] = next state << 6 | symbols completed inside the nibble (0..2) | their bytes << 16.  Every lane
 //     takes exactly 64 steps per subsequence, whatever the code lengths: no divergence, no ballots, no branches, no
 //     escape path for long codewords (a 21-bit codeword is six ordinary steps), straight-line code;
@@ -15,13 +15,17 @@
 //     look-ahead: a codeword that crosses a subsequence boundary is carried by the STATE, so a subsequence's entry and exit
 //     are automaton states instead of bit offsets and the fixed point "my entry = my left neighbour's exit" is iterated
 //     on states (first one exact; converges like codeword synchronisation does: 2 walks per window on text);
-//   * a walk (phase A) is 5 vector + 1 LDS instruction per step and counts the symbols that COMPLETE inside the
-//     subsequence; the output pass (phase B) is the same walk with two byte stores per step into the tile at the offsets
-//     of the scan.
-// Not handled here (the block is left to k4_decode.hip's medium-class kernel, decided from the length table alone):
-// tables with a 1-bit codeword (a nibble could complete three or four symbols), tables whose code tree has more than 254
-// internal nodes (foreign incomplete tables only).  A window that is not synchronised after DCZ_K4_EXACT_AFTER rounds
-// hands its block to the exact-entry launch, as everywhere.
+//   * round 0 is an exit-only walk over the subsequence's last 48 nibbles (1 vector + 1 LDS instruction per step), round 1
+//     walks everything from the neighbour's exit and counts the symbols that COMPLETE inside the subsequence (3 + 1),
+//     the output pass (phase B) is the same walk collecting the symbols in a register and storing whole dwords into the
+//     tile at the offsets of the scan (9 + 1.25).
+// Instantiations: MODE 0 one workgroup per block (256 threads, or 1024 for few blocks), MODE 1 / MODE 2 the decoding and
+// the counting pass of the split decoder (one workgroup per region, k4_split.hip), SPARSE the variant for blocks dominated
+// by a 1-bit symbol (up to four symbols per nibble, no tile).
+// Not handled here (the block is left to k4_decode.hip's kernels, decided from the length table alone): tables with a
+// 1-bit codeword that are not sparse (a nibble could complete three or four symbols), tables whose code tree has more
+// than 255 internal nodes (foreign incomplete tables, or 256 symbols in a deep tree).  A window that is not synchronised
+// after DCZ_K4_EXACT_AFTER rounds hands its block to the exact-entry launch, as everywhere.
 #include <cstdlib>
 #include <utility>
 
