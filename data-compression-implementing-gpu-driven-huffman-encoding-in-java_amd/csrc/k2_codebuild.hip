@@ -53,6 +53,9 @@ __device__ __forceinline__ void heap_offer(unsigned long long* q, int& size, uns
 }
 
 // PriorityQueue.poll -> siftDown: ties prefer the left child; x stops when x <= child.
+// (Measured with DCZ_K2_PROF / tools/k2prof.py: the serial build is 90-97 % of a block's K2 time, ~250 cycles per heap
+// level.  Fetching children and grandchildren together -- two levels per LDS round trip -- changed nothing: a level's cost
+// is its chain of ~30 dependent 64-bit vector/scalar instructions and branches on a SIMD that holds one wave, not the read.)
 __device__ __forceinline__ unsigned long long heap_poll(unsigned long long* q, int& size) {
     const unsigned long long result = q[1];
     const int n = --size;
@@ -213,6 +216,17 @@ __device__ void canonical_codes(CodeLds& L, uint32_t* __restrict__ out, bool zer
     __syncthreads();
 }
 
+#if DCZ_K2_PROF
+__device__ unsigned long long k2_prof[8];  // cycles of wave 0's lane 0 per phase, summed over blocks; [7] = blocks
+#define K2_T_(i)                                           \
+    do {                                                   \
+        const unsigned long long t_ = clock64();           \
+        if (tid == 0) atomicAdd(&k2_prof[i], t_ - plast);  \
+        plast = t_;                                        \
+    } while (0)
+#else
+#define K2_T_(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict__ seg_hist,
                                                      const long long* __restrict__ hist_in, size_t n,
                                                      size_t block_bytes, uint32_t spb, uint32_t K,
@@ -225,6 +239,10 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
     const uint32_t b = blockIdx.x;
     const int tid = (int)threadIdx.x;
 
+#if DCZ_K2_PROF
+    unsigned long long plast = clock64();
+    if (tid == 0) atomicAdd(&k2_prof[7], 1ull);
+#endif
     // number of segments this block really has (the last block may be short)
     uint32_t nsb = 0;
     if (seg_hist) {
@@ -250,7 +268,9 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
         for (int i = 0; i < 4; i++) hf[i] = (unsigned long long)hist_in[(uint64_t)b * 256u + 4 * tid + i];
     }
 
+    K2_T_(0);
     build_lengths(L, hf);
+    K2_T_(1);
     const int maxlen = L.maxlen;
     const bool too_long = maxlen > 32;  // core/CanonicalHuffman.java:102-106 would throw
     if (too_long) {
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
     }
     __syncthreads();
     canonical_codes(L, d_code + (uint64_t)b * 256u, false);
+    K2_T_(2);
     unsigned long long bits = 0;
     {
         uint32_t l4 = 0;
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
         d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
     }
 
+    K2_T_(3);
     // per-segment bit offsets inside the block: exclusive scan of bits(segment) = sum_s seg_hist[seg][s] * len[s]
     if (seg_hist && d_seg_bitoff) {
         unsigned long long carry = 0;
@@ -306,6 +328,7 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
             carry += tot;
         }
     }
+    K2_T_(4);
     (void)K;
 }
 
@@ -389,3 +412,13 @@ void launch_offsets(const uint32_t* d_comp_size, uint32_t K, uint64_t* d_comp_of
 }
 
 }  // namespace dcz
+
+#if DCZ_K2_PROF
+extern "C" void dcz_debug_k2_prof(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::k2_prof), sizeof(dcz::k2_prof));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(dcz::k2_prof), z, sizeof(z));
+    }
+}
+#endif
