@@ -68,7 +68,7 @@ namespace dcz {
                                    // same: 3.12 vs 3.02 ms -- the kernel is bound by its write traffic, not by the wait)
 #endif
 #ifndef DCZ_DFA_ABL
-#define DCZ_DFA_ABL 0  // timing ablations (WRONG output): 1 = phase B stores all go to the dummy bytes, 2 = no phase B stores,
+#define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
 #ifndef DCZ_DFA_MINWAVES
 #define DCZ_DFA_MINWAVES 4
