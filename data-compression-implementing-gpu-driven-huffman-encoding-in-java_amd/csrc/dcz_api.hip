@@ -49,8 +49,15 @@ struct dcz_ctx {
         const uint32_t seen = hint_host[which];
         // unknown on the first call; afterwards "likely" while a call of the last 8 had such a block
         h.likely = h.epoch <= 1u || (seen != 0u && seen + 8u >= h.epoch);
+        if (which == 1 && in_place_ok) {
+            // K1 stores the input at the same offsets of the output when the last calls had identity blocks and none
+            // had anything else (word 2: sequence number of the last call with a block of another kind)
+            const uint32_t other = hint_host[2];
+            h.in_place = seen != 0u && seen + 8u >= h.epoch && (other == 0u || other + 8u < h.epoch);
+        }
         return h;
     }
+    bool in_place_ok = true;  // DCZ_NO_IN_PLACE=1 turns the speculation off
     void* pinned[2] = {nullptr, nullptr};  // pinned host staging handed out by dcz_ctx_pinned (grow-only)
     size_t pinned_cap[2] = {0, 0};
     // profiling
@@ -61,8 +68,8 @@ struct dcz_ctx {
     };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
-    double ms[DCZ_K_COUNT] = {0, 0, 0, 0, 0};
-    uint64_t launches[DCZ_K_COUNT] = {0, 0, 0, 0, 0};
+    double ms[DCZ_K_COUNT] = {0, 0, 0, 0, 0, 0};
+    uint64_t launches[DCZ_K_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -286,6 +293,7 @@ int dcz_ctx_create(int device, dcz_ctx** out) {
             }
         }
     }
+    if (const char* ni = std::getenv("DCZ_NO_IN_PLACE")) c->in_place_ok = !(ni[0] && ni[0] != '0');
     if (const char* np = std::getenv("DCZ_NO_PIPELINE")) c->pipeline = !(np[0] && np[0] != '0');
     if (!ok) {
         dcz_ctx_destroy(c);
@@ -381,14 +389,17 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
         *len_b = end - *off_b;
         *seg0 = (uint64_t)k0 * g.spb;
     };
+    ShapeHint enc_hint = c->next_hint(1);
+    // the copy needs room for the whole input at its own offsets, and 16-byte units that are aligned in both buffers
+    if (out_cap < n || ((reinterpret_cast<uintptr_t>(in) - reinterpret_cast<uintptr_t>(out)) & 15u) != 0u) enc_hint.in_place = false;
     auto k1 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
         size_t ob, lb;
         uint64_t s0;
         range(k0, kn, &ob, &lb, &s0);
-        KernelTimer t(c, st, DCZ_K_HISTOGRAM);
-        launch_histogram(in + ob, lb, block_bytes, g.spb, (uint64_t)kn * g.spb, c->seg_hist + s0 * 256u, st);
+        KernelTimer t(c, st, enc_hint.in_place ? DCZ_K_HISTOGRAM_COPY : DCZ_K_HISTOGRAM);
+        launch_histogram(in + ob, lb, block_bytes, g.spb, (uint64_t)kn * g.spb, c->seg_hist + s0 * 256u, st,
+                         enc_hint.in_place ? out + ob : nullptr);
     };
-    const ShapeHint enc_hint = c->next_hint(1);
     auto k2 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
         size_t ob, lb;
         uint64_t s0;
@@ -407,8 +418,10 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
             launch_offsets(d_comp_size + k0, kn, d_comp_off + k0, total_out, carry_in, out_cap, d_status + k0, st);
         }
         KernelTimer t(c, st, DCZ_K_ENCODE);
+        ShapeHint eh = enc_hint;
+        eh.in_offset = ob;
         launch_encode(in + ob, lb, block_bytes, g.spb, kn, d_len + (size_t)k0 * 256u, c->code + (size_t)k0 * 256u,
-                      c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st, enc_hint);
+                      c->maxlen + k0, d_comp_off + k0, c->seg_bitoff + s0, d_status + k0, out, st, eh);
     };
     static const uint32_t pipeline_min_k = [] {
         const char* e = getenv("DCZ_PIPELINE_MIN_K");  // tuning knob

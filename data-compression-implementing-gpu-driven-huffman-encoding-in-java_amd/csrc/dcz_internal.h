@@ -15,7 +15,7 @@ constexpr int WAVE = 64;                     // gfx950 wavefront
 // ---- host-side launchers (each defined next to its kernel) ---------------------------------
 // K1: per-segment 256-bin histograms.  seg_hist is [nseg][256] u16 (a segment holds <= 32768 bytes).
 void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint64_t nseg,
-                      uint16_t* seg_hist, hipStream_t s);
+                      uint16_t* seg_hist, hipStream_t s, uint8_t* copy_out = nullptr);
 // Histogram of a byte window into 256 x i64 (single-block API; sums the segment rows on the device).
 void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s);
 
@@ -30,6 +30,12 @@ struct ShapeHint {
     uint32_t* dev = nullptr;  // device address of the word (nullptr: nothing is recorded)
     uint32_t epoch = 0;       // this call's sequence number (> 0)
     bool likely = true;       // flat grid
+    // Encoder only.  dev[1] (the word after dev's) receives the sequence number of calls that had a block WITHOUT the
+    // identity code.  `in_place`: K1 copied the input to the output at the same offsets (launch_histogram's copy_out) because
+    // the calls before had nothing but identity blocks; k3_copy_identity then leaves alone every identity block whose payload
+    // offset equals its input offset.
+    bool in_place = false;
+    unsigned long long in_offset = 0;  // byte offset, inside the call's input, of the block range a launch covers
 };
 constexpr uint32_t HINT_PERSIST_GRID = 1024;
 

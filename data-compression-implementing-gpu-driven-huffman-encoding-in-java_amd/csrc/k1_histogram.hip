@@ -25,6 +25,12 @@ namespace dcz {
 #define DCZ_K1_NT 1  // read-once stream: non-temporal loads.  With the next step's loads issued ahead: 0.79 -> 0.72 ms per
                      // 4 GiB (6.0 TB/s); without that, and for 4 instead of 6 vector instructions per byte, no difference
 #endif
+#ifndef DCZ_K1_COPY_NT
+#define DCZ_K1_COPY_NT 1
+#endif
+#ifndef DCZ_K1_COPY_LATE
+#define DCZ_K1_COPY_LATE 1
+#endif
 #ifndef DCZ_K1_WAVES
 #define DCZ_K1_WAVES 4
 #endif
@@ -69,9 +75,16 @@ __device__ __forceinline__ void hist_add_vec(uint32_t* h, uint32_t col, const ui
     hist_add_dword(h, col, v.w);
 }
 
+// COPY: the segment is also stored, byte for byte, at the same offset of copy_out.  That is the whole encoder output when
+// every block of the call turns out to have the identity code (256 symbols of 8 bits: the reference's high-entropy case,
+// payload = input, block b at offset b * block_bytes); the caller asks for it when the calls before were like that
+// (ShapeHint, dcz_internal.h) and K3 then finds its blocks already in place -- one read and one write of the input
+// instead of two reads and one write.  If a block is not of that kind after all, K3 writes it as always.
+template <bool COPY>
 __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __restrict__ in, size_t n,
                                                                size_t block_bytes, uint32_t spb, uint64_t nseg,
-                                                               uint16_t* __restrict__ seg_hist) {
+                                                               uint16_t* __restrict__ seg_hist,
+                                                               uint8_t* __restrict__ copy_out) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[K1_WAVES][K1_DW];
     const int w = (int)(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -99,8 +112,32 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
     // unaligned head (only when block_bytes or the base pointer is not a multiple of 16)
     uint32_t nhead = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
     if (nhead > len) nhead = len;
-    if ((uint32_t)lane < nhead) hist_add(h, col, p[lane]);
+    if ((uint32_t)lane < nhead) {
+        const uint8_t v = p[lane];
+        hist_add(h, col, v);
+        if constexpr (COPY) copy_out[s0 + lane] = v;
+    }
     const uint4* pv = reinterpret_cast<const uint4*>(p + nhead);
+    // (COPY: the caller guarantees copy_out - in is a multiple of 16, so these units are aligned in both buffers)
+    u32x4* const cv = COPY ? reinterpret_cast<u32x4*>(copy_out + s0 + nhead) : nullptr;
+    auto store4 = [&](uint32_t base, const uint4& d0, const uint4& d1, const uint4& d2, const uint4& d3) {
+        if constexpr (COPY) {
+            const uint32_t i0 = base + (uint32_t)lane;
+            const u32x4 a = {d0.x, d0.y, d0.z, d0.w}, b2 = {d1.x, d1.y, d1.z, d1.w};
+            const u32x4 c = {d2.x, d2.y, d2.z, d2.w}, e = {d3.x, d3.y, d3.z, d3.w};
+#if DCZ_K1_COPY_NT
+            __builtin_nontemporal_store(a, cv + i0);
+            __builtin_nontemporal_store(b2, cv + i0 + 64);
+            __builtin_nontemporal_store(c, cv + i0 + 128);
+            __builtin_nontemporal_store(e, cv + i0 + 192);
+#else
+            cv[i0] = a;
+            cv[i0 + 64] = b2;
+            cv[i0 + 128] = c;
+            cv[i0 + 192] = e;
+#endif
+        }
+    };
     const uint32_t nvec = (len - nhead) >> 4;
 
     // body: 4 x 16 B per lane per step, the next step's loads issued before this step's atomics (a wave alternates between
@@ -128,21 +165,38 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
     for (uint32_t base = 0; base < nfull; base += 256) {
         uint4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
         if (base + 256 < nfull) load4(base + 256, n0, n1, n2, n3);
+#if !DCZ_K1_COPY_LATE
+        store4(base, c0, c1, c2, c3);
+#endif
         hist_add_vec(h, col, c0);
         hist_add_vec(h, col, c1);
         hist_add_vec(h, col, c2);
         hist_add_vec(h, col, c3);
+#if DCZ_K1_COPY_LATE
+        store4(base, c0, c1, c2, c3);
+#endif
         c0 = n0;
         c1 = n1;
         c2 = n2;
         c3 = n3;
     }
-    for (uint32_t i = nfull + (uint32_t)lane; i < nvec; i += 64) hist_add_vec(h, col, pv[i]);  // the ragged last step
+    for (uint32_t i = nfull + (uint32_t)lane; i < nvec; i += 64) {  // the ragged last step
+        const uint4 v = pv[i];
+        hist_add_vec(h, col, v);
+        if constexpr (COPY) {
+            const u32x4 a = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(a, cv + i);
+        }
+    }
     // tail (< 16 bytes)
     {
         const uint32_t done = nhead + (nvec << 4);
         const uint32_t ntail = len - done;
-        if ((uint32_t)lane < ntail) hist_add(h, col, p[done + lane]);
+        if ((uint32_t)lane < ntail) {
+            const uint8_t v = p[done + lane];
+            hist_add(h, col, v);
+            if constexpr (COPY) copy_out[s0 + done + lane] = v;
+        }
     }
     wave_lds_fence();
 
@@ -180,11 +234,15 @@ __global__ __launch_bounds__(256) void k1_sum_rows(const uint16_t* __restrict__ 
 }
 
 void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t segs_per_block, uint64_t nseg,
-                      uint16_t* seg_hist, hipStream_t s) {
+                      uint16_t* seg_hist, hipStream_t s, uint8_t* copy_out) {
     if (nseg == 0) return;
     const uint32_t grid = (uint32_t)((nseg + K1_WAVES - 1) / K1_WAVES);
-    hipLaunchKernelGGL(k1_histogram, dim3(grid), dim3(K1_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block, nseg,
-                       seg_hist);
+    if (copy_out)
+        hipLaunchKernelGGL(k1_histogram<true>, dim3(grid), dim3(K1_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block,
+                           nseg, seg_hist, copy_out);
+    else
+        hipLaunchKernelGGL(k1_histogram<false>, dim3(grid), dim3(K1_WAVES * 64), 0, s, d_in, n, block_bytes, segs_per_block,
+                           nseg, seg_hist, (uint8_t*)nullptr);
 }
 
 void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s) {

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(K2_T) void k2_codebuild(const uint16_t* __restrict_
         // bit 7: 256 symbols of 8 bits, i.e. codeword(s) = s and the payload is a copy of the input (K3 copies it)
         const bool identity = !too_long && maxlen == 8 && L.nsym == 256;
         d_maxlen[b] = (uint8_t)(too_long ? 0 : (maxlen | (identity ? 0x80 : 0)));
-        if (identity && hint) *hint = epoch;  // (ShapeHint: k3_copy_identity has work in calls like this one)
+        if (hint) hint[identity ? 0 : 1] = epoch;  // (ShapeHint: calls like this one have / do not only have identity blocks)
         d_comp_size[b] = too_long ? 0u : (uint32_t)((bits + 7) >> 3);
         d_status[b] = too_long ? DCZ_E_CODELEN : DCZ_OK;
     }

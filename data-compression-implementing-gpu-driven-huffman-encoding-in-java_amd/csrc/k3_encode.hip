@@ -415,10 +415,12 @@ static_assert(CP_UPT >= 1 && CP_UPT * CP_T * 16 == (int)CP_TILE, "tile = threads
 __device__ __forceinline__ void copy_identity_item(uint32_t bq, uint32_t tile, const uint8_t* __restrict__ in, size_t n,
                                                    size_t block_bytes, uint32_t b0, const uint8_t* __restrict__ d_maxlen,
                                                    const unsigned long long* __restrict__ d_comp_off,
-                                                   const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
+                                                   const int32_t* __restrict__ d_status, uint8_t* __restrict__ out,
+                                                   bool in_place, unsigned long long in_offset) {
     const uint32_t b = b0 + bq;
     if ((d_maxlen[b] & 0x80u) == 0u || d_status[b] != DCZ_OK) return;  // workgroup-uniform
     const uint64_t bstart = (uint64_t)b * block_bytes;
+    if (in_place && d_comp_off[b] == in_offset + bstart) return;  // K1 stored this block where it belongs (ShapeHint)
     const uint64_t bend = (bstart + block_bytes < n) ? bstart + block_bytes : (uint64_t)n;
     const uint64_t t0 = (uint64_t)tile * CP_TILE;
     if (bstart + t0 >= bend) return;
@@ -451,21 +453,24 @@ __global__ __launch_bounds__(CP_T) void k3_copy_identity(const uint8_t* __restri
                                                          uint32_t tiles_per_block, uint32_t b0, uint32_t nblk,
                                                          const uint8_t* __restrict__ d_maxlen,
                                                          const unsigned long long* __restrict__ d_comp_off,
-                                                         const int32_t* __restrict__ d_status, uint8_t* __restrict__ out) {
+                                                         const int32_t* __restrict__ d_status, uint8_t* __restrict__ out,
+                                                         bool in_place, unsigned long long in_offset) {
     if constexpr (!PERSIST) {
         const uint32_t bq = blockIdx.x / tiles_per_block;
-        copy_identity_item(bq, blockIdx.x - bq * tiles_per_block, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out);
+        copy_identity_item(bq, blockIdx.x - bq * tiles_per_block, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out,
+                           in_place, in_offset);
     } else {
         // CP_T blocks at a time: all threads look at one flag each, and a range without a flagged block is skipped whole
         for (uint32_t c0 = 0; c0 < nblk; c0 += (uint32_t)CP_T) {
             const uint32_t bi = c0 + threadIdx.x;
-            const int mine = bi < nblk && (d_maxlen[b0 + bi] & 0x80u) != 0u;
+            const int mine = bi < nblk && (d_maxlen[b0 + bi] & 0x80u) != 0u &&
+                             !(in_place && d_comp_off[b0 + bi] == in_offset + (unsigned long long)(b0 + bi) * block_bytes);
             if (!__syncthreads_or(mine)) continue;  // workgroup-uniform
             const uint32_t c1 = (nblk - c0 < (uint32_t)CP_T) ? nblk : c0 + (uint32_t)CP_T;
             for (uint32_t bq = c0; bq < c1; bq++) {
                 if ((d_maxlen[b0 + bq] & 0x80u) == 0u) continue;
                 for (uint32_t tile = blockIdx.x; tile < tiles_per_block; tile += gridDim.x)
-                    copy_identity_item(bq, tile, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out);
+                    copy_identity_item(bq, tile, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out, in_place, in_offset);
             }
         }
     }
@@ -476,13 +481,13 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
                    const uint64_t* d_seg_bitoff, const int32_t* d_status, uint8_t* d_out, hipStream_t s,
                    const ShapeHint& hint) {
     if (K == 0) return;
-    if (!hint.likely) {
+    if (!hint.likely || hint.in_place) {  // (in place: nothing is expected to be left for this kernel)
         const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;
         const uint64_t tpb = (eff + CP_TILE - 1) / CP_TILE;
         if (tpb <= 0xFFFFFFFFull)
             hipLaunchKernelGGL(k3_copy_identity<true>, dim3(HINT_PERSIST_GRID), dim3(CP_T), 0, s, d_in, n, block_bytes,
                                (uint32_t)tpb, 0u, K, d_maxlen, reinterpret_cast<const unsigned long long*>(d_comp_off),
-                               d_status, d_out);
+                               d_status, d_out, hint.in_place, hint.in_offset);
     } else {
         const size_t eff = (K <= 1) ? (n ? n : 1) : block_bytes;
         const uint64_t tpb = (eff + CP_TILE - 1) / CP_TILE;
@@ -491,7 +496,7 @@ void launch_encode(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_t s
             const uint64_t kb = (K - b0 < per) ? K - b0 : per;
             hipLaunchKernelGGL(k3_copy_identity<false>, dim3((uint32_t)(kb * tpb)), dim3(CP_T), 0, s, d_in, n, block_bytes,
                                (uint32_t)tpb, (uint32_t)b0, (uint32_t)kb, d_maxlen,
-                               reinterpret_cast<const unsigned long long*>(d_comp_off), d_status, d_out);
+                               reinterpret_cast<const unsigned long long*>(d_comp_off), d_status, d_out, false, 0ull);
         }
     }
     const uint32_t gpb = (segs_per_block + K3_WAVES - 1) / K3_WAVES;

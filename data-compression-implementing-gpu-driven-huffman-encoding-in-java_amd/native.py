@@ -16,8 +16,9 @@ DCZ_E_CODELEN = -6
 DCZ_E_BADTABLE = -7
 
 K_HISTOGRAM, K_CODEBUILD, K_OFFSETS, K_ENCODE, K_DECODE = range(5)
+K_HISTOGRAM_COPY = 5
 KERNEL_NAMES = {K_HISTOGRAM: "k1_histogram", K_CODEBUILD: "k2_codebuild", K_OFFSETS: "k2_offsets",
-                K_ENCODE: "k3_encode", K_DECODE: "k4_decode"}
+                K_ENCODE: "k3_encode", K_DECODE: "k4_decode", K_HISTOGRAM_COPY: "k1_histogram_copy"}
 SEGMENT_BYTES = 32768
 
 # every symbol include/dcz.h declares (tests check the .so exports each one)

@@ -107,7 +107,11 @@ int dcz_decode_block(dcz_ctx* ctx, const uint8_t* comp, size_t comp_size, const 
  *   d_len       K x 256 x u8 code lengths                         (core/CompressionHeader.java:80-83)
  *   d_status    K x i32  DCZ_OK / DCZ_E_CODELEN / DCZ_E_CAPACITY per chunk
  *   d_total     1 x u64  sum of compressedSize (may be NULL)
- * All pointers are device pointers.  Asynchronous on `stream`; no host synchronisation. */
+ * All pointers are device pointers.  Asynchronous on `stream`; no host synchronisation.
+ * d_out[0, min(out_cap, n)) may be written anywhere by the call, not only inside [0, *d_total): when the calls before had
+ * nothing but chunks whose code is 256 symbols of 8 bits (payload = input), the histogram pass also stores the input at
+ * its own offsets of d_out (valid payload if this call is like them; overwritten by the encoder where it is not).  That
+ * needs out_cap >= n and d_in - d_out a multiple of 16; DCZ_NO_IN_PLACE=1 turns it off. */
 int dcz_compress_blocks(dcz_ctx* ctx, const void* d_in, size_t n, size_t block_bytes, void* d_out,
                         size_t out_cap, uint32_t* d_comp_size, uint64_t* d_comp_off, uint8_t* d_len,
                         int32_t* d_status, uint64_t* d_total, void* stream);
@@ -161,7 +165,10 @@ enum {
     DCZ_K_OFFSETS = 2,   /* payload offset scan */
     DCZ_K_ENCODE = 3,    /* K3 */
     DCZ_K_DECODE = 4,    /* K4 */
-    DCZ_K_COUNT = 5
+    DCZ_K_HISTOGRAM_COPY = 5, /* K1 that also stores the input at the same offsets of the output: launched instead of K1
+                               * when the calls before had nothing but blocks whose code is 256 symbols of 8 bits (payload =
+                               * input, the reference's high-entropy case); K3 then finds those blocks in place */
+    DCZ_K_COUNT = 6
 };
 
 /* When on, every kernel launch is bracketed by hipEvents on its own stream (the per-stage timers

@@ -1372,3 +1372,55 @@ def test_launch_shape_hint_both_shapes_on_both_kinds_of_input(pkg, orc):
         assert_parity(svc, orc, data, 65536)
         if i % 4 == 3:
             torch.cuda.synchronize()  # (let some hints arrive, leave others in flight)
+
+
+def test_identity_blocks_are_stored_in_place_by_the_histogram_pass(pkg, orc):
+    """After calls whose blocks all had the identity code (256 symbols of 8 bits), K1 also stores the input at the same
+    offsets of the output and K3 leaves those blocks alone (DCZ_K_HISTOGRAM_COPY).  The decision rests on what earlier
+    calls found, so every way it can be wrong must still give the oracle's bytes: a call with other blocks mixed in, a
+    ragged last block, an input that is not aligned like the output, an output that is too small for the copy."""
+    torch = _torch()
+    svc = pkg.HipCompressionService(1, 0)  # a context of its own: the hint is per context
+    svc.ctx.set_profiling(True)
+    K_COPY, bb = pkg.native.K_HISTOGRAM_COPY, 65536
+    rnd = orc.java_random_bytes(31, 24 * bb)
+    for i in range(14):  # all blocks identity: the later calls run the fused kernel
+        assert_parity(svc, orc, rnd if i % 2 else orc.java_random_bytes(100 + i, 24 * bb), bb)
+        torch.cuda.synchronize()
+    assert svc.ctx.kernel_time(K_COPY)[1] > 0, "the fused K1 never ran on fourteen all-identity calls"
+    mixed = np.concatenate([rnd[:8 * bb], orc.gen_text(3, 0, 4 * bb), rnd[8 * bb:14 * bb]])
+    assert_parity(svc, orc, mixed, bb)                        # speculated, wrong for four blocks: K3 writes everything that moved
+    torch.cuda.synchronize()
+    before = svc.ctx.kernel_time(K_COPY)[1]
+    assert_parity(svc, orc, rnd, bb)                          # the call before had other blocks: no speculation now
+    torch.cuda.synchronize()
+    assert svc.ctx.kernel_time(K_COPY)[1] == before
+    for i in range(12):
+        assert_parity(svc, orc, rnd, bb)
+        torch.cuda.synchronize()
+    assert svc.ctx.kernel_time(K_COPY)[1] > before             # ... and back again
+    assert_parity(svc, orc, rnd[: 20 * bb + 4321], bb)        # ragged last block (not identity)
+    for i in range(10):
+        assert_parity(svc, orc, rnd, bb)
+        torch.cuda.synchronize()
+    # input misaligned against the output: no copy, same bytes
+    t = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), rnd])).cuda()
+    n0 = svc.ctx.kernel_time(K_COPY)[1]
+    blk = svc.compress_device(t[3:], bb)
+    torch.cuda.synchronize()
+    assert svc.ctx.kernel_time(K_COPY)[1] == n0
+    opay, _, _, _ = orc.compress_blocks(rnd, bb)
+    assert (blk.payload[: int(blk.total.item())].cpu().numpy() == opay).all()
+    # output too small for the copy (and for the payload): per-chunk capacity errors as ever, nothing past the capacity
+    out = pkg.DeviceBlocks(torch.zeros(10 * bb + 100, dtype=torch.uint8, device="cuda"),
+                           torch.zeros(24, dtype=torch.int32, device="cuda"), torch.zeros(24, dtype=torch.int64, device="cuda"),
+                           torch.zeros((24, 256), dtype=torch.uint8, device="cuda"),
+                           torch.zeros(24, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                           rnd.size, bb)
+    guard = torch.full((4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    svc.compress_device(torch.from_numpy(rnd).cuda(), bb, out=out)
+    torch.cuda.synchronize()
+    st = out.status.cpu().numpy()
+    assert list(st[:10]) == [0] * 10 and (st[10:] == pkg.native.DCZ_E_CAPACITY).all()
+    assert (out.payload[: 10 * bb].cpu().numpy() == rnd[: 10 * bb]).all()
+    assert bool((guard == 0x5A).all())

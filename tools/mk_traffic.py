@@ -8,7 +8,8 @@ build = sys.argv[5] if len(sys.argv) > 5 else ""
 # kernel family -> (name fragments, launches of EACH of its kernels per bench step).  The compress call runs as two
 # pipelined halves when it has >= 2048 chunks; one decode call launches every K4 kernel once.
 halves = 2 if per_gpu // chunk >= 2048 else 1
-fam = {"k1_histogram": (["k1_histogram"], halves), "k3_encode": (["k3_encode", "k3_copy_identity"], halves),
+fam = {"k1_histogram": (["k1_histogram<false>"], halves), "k1_histogram_copy": (["k1_histogram<true>"], halves),
+       "k3_encode": (["k3_encode", "k3_copy_identity"], halves),
        "k4_decode": (["k4_decode", "k4_fixed", "k4_classify", "k4_split", "k4_regwin"], 1)}
 res = {}
 for k, (frags, per_step) in fam.items():
@@ -21,7 +22,7 @@ for k, (frags, per_step) in fam.items():
                     name = r["Kernel_Name"].split("(")[0]
                     tot[name] += float(r["Counter_Value"]) * mul
                     cnt[name] += 1
-        res[k][key] = int(sum(tot[n] / cnt[n] for n in tot) * per_step)
+        res[k][key] = int(sum(tot[n] / cnt[n] for n in tot) * per_step)  # (a family that never ran: 0)
     res[k]["total"] = res[k]["read"] + res[k]["write"]
 path = "profiles/pmc_traffic.json"
 try:
