@@ -28,4 +28,19 @@ for i in range(iters):
         del t, blk, out
     if i % 5 == 4:
         print("iteration", i + 1, "failures", bad, flush=True)
-print("soak done:", iters, "iterations x", len(shapes), "shapes, failures:", bad)
+# runs of all-identity calls (the fused K1 stores the payload in place) broken by calls of other kinds
+name, fill, seed, n, bb = shapes[2]
+for i in range(3 * iters):
+    kind = shapes[1] if i % 13 == 12 else shapes[2]
+    t = torch.empty(n if kind is shapes[2] else kind[3], dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    kind[1](h, t.data_ptr(), t.numel(), kind[2] + 1000 + i, 0, None)
+    blk = svc.compress_device(t, kind[4])
+    K = blk.num_chunks
+    orig = torch.full((K,), kind[4], dtype=torch.int32, device="cuda")
+    out, st, ep = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, kind[4])
+    if not (bool(torch.equal(out[:t.numel()], t)) and int(st.abs().max()) == 0):
+        bad += 1
+        print("MISMATCH in-place run", i, kind[0], flush=True)
+    del t, blk, out
+print("soak done:", iters, "iterations x", len(shapes), "shapes +", 3 * iters, "calls in identity runs, failures:", bad)
