@@ -13,7 +13,7 @@
 // k4_classify runs first on every decode call (one thread per block): validates the untrusted footer fields against the
 // buffers (DCZ_E_INVALID, no kernel touches such a block) and flags fixed-length blocks (class byte 0x10 | L); the
 // table-walk kernels of k4_decode.hip skip every block whose class byte is not 0.
-// k4_fixed is a FLAT grid of one workgroup per (block, 16 KiB output tile) over all blocks; a workgroup whose block is not
+// k4_fixed is a FLAT grid of one workgroup per (block, 8 KiB output tile) over all blocks; a workgroup whose block is not
 // of the class leaves after one byte load.  Measured on MI355X (tools/micro/copybench.hip, 8 GiB): a flat grid of small
 // tiles copies at 6.1-6.6 TB/s with non-temporal accesses, persistent grid-stride loops reach 4.5-5.5 TB/s (inside one
 // wave a load's data waits for every older store: vmcnt counts them in order), and 512 K workgroups that leave at once
@@ -24,17 +24,18 @@
 
 namespace dcz {
 
-// Work item shape.  One 16-byte access per lane copies fastest in isolation (tools/micro/copybench2.hip, 8 GiB, flat grids,
-// non-temporal: 256 threads x 4 per lane 6.06 TB/s, 1024 x 1 6.39, 512 x 1 6.53, 256 x 1 with 4 KiB tiles 6.60), but it
-// takes four times the waves, and the waves of a launch that finds no fixed-length block cost what they cost: measured in
-// the library, 512 x 1 with 8 KiB tiles gains 0.1 ms per 4 GiB on the identity copy of K3 and nothing here, and adds
-// 0.1-0.15 ms per 4 GiB to every launch on text and low-entropy input.  So: 256 threads, four accesses per lane.
+// Work item shape.  One 16-byte access per lane copies fastest (tools/micro/copybench2.hip, 8 GiB, flat grids, non-temporal:
+// 256 threads x 4 per lane 6.06 TB/s, 1024 x 1 6.39, 512 x 1 6.53, 256 x 1 with 4 KiB tiles 6.60), but takes four times the
+// waves, and the waves of a launch that finds no fixed-length block cost what they cost (0.1-0.15 ms per 4 GiB on text
+// and low-entropy input) -- which the launch-shape hint now avoids: such calls get the small persistent grid.  In the
+// library, three runs each: 512 threads x 1 with 8 KiB tiles K4 2.91-2.92 ms per 8 GiB, 1024 x 1 with 16 KiB 2.94-2.96,
+// 256 x 4 with 16 KiB 3.02-3.03.
 #ifndef DCZ_FX_TILE
-#define DCZ_FX_TILE 16384
+#define DCZ_FX_TILE 8192
 #endif
 constexpr uint32_t FX_TILE = DCZ_FX_TILE;  // output bytes per work item
 #ifndef DCZ_FX_T
-#define DCZ_FX_T 256
+#define DCZ_FX_T 512
 #endif
 constexpr int FX_T = DCZ_FX_T;
 constexpr int FX_UPT = (int)(FX_TILE / 16u / (uint32_t)FX_T);  // 16-byte units per thread
