@@ -9,7 +9,9 @@ One "step" = one pass of the hot path over this rank's batch, inputs resident in
   K1 histogram -> K2 code build -> payload offsets -> K3 encode -> [all-gather of per-chunk sizes, N > 1]
   -> K4 decode.  value = (bytes all ranks processed) / (max over ranks of the timed region).
 Weak scaling: every rank holds `--bytes-per-gpu` of the stream (rank r owns the r-th contiguous chunk range).
-Rank 0 prints ONE JSON line.  At N = 1 rank 0 also times the CPU oracle on a bounded sample (cpu_baseline).
+Rank 0 prints ONE JSON line.  The headline fields describe `--workload` (default: the north-star target); the other
+BASELINE.json configurations are timed after it with a few steps each and reported under "secondary" of the same line,
+each with its own roofline.  At N = 1 rank 0 also times the CPU oracle on a bounded sample (cpu_baseline).
 """
 import argparse
 import json
@@ -41,61 +43,55 @@ WORKLOADS = {
     "text8g": ("text", 0xD0C2, 8 << 30, 4 << 20,
                "8GiB/GPU order-0 English-like text, 4MiB chunks [BASELINE config 4 at one GPU's worth of 8 GiB]"),
 }
+# what the default run times after the headline workload (name, steps, warm-up)
+SECONDARY_1GPU = [("text8g", 5, 3), ("lowentropy", 5, 3), ("random256m", 20, 5), ("text", 10, 3), ("text_32m", 10, 3)]
+SECONDARY_NGPU = [("text", 10, 3), ("lowentropy", 5, 3)]  # configs 4 and 5 exactly, at N = 8
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="random8g", choices=sorted(WORKLOADS))
-    ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the workload's per-GPU bytes")
-    ap.add_argument("--chunk-bytes", type=int, default=0)
-    ap.add_argument("--cpu-sample-mib", type=int, default=-1,
-                    help="MiB of the stream the CPU oracle is timed on; -1 = auto (10-30 s of CPU work), 0 = off")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only exists "
-                         "to rehearse the N>1 code path on a one-GPU box")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+class Env:
+    """Process-wide pieces every workload shares."""
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.np, self.torch, self.dist, self.args = np, torch, dist, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, self.world, args.gpus))
+        if args.single_device:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)  # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        self.pkg = entry.load_package()  # raises if libdczhip.so is missing: no fallback
+        from dcz_amd import sharding
+        self.sharding = sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    pkg = entry.load_package()  # raises if libdczhip.so is missing: no fallback
-    from dcz_amd import sharding
-
-    gen, seed, per_gpu, chunk, desc = WORKLOADS[args.workload]
-    if args.bytes_per_gpu:
-        per_gpu = args.bytes_per_gpu
-    if args.chunk_bytes:
-        chunk = args.chunk_bytes
+def run_workload(env, name, steps, warmup, verify, per_gpu_override=0, chunk_override=0):
+    """Times `steps` steps of one workload on a context of its own (the launch-shape hints are per context, so a
+    workload starts like a fresh process would).  Returns the result dict of rank 0's view, value aggregated over ranks."""
+    torch, dist, pkg, world, rank, dev = env.torch, env.dist, env.pkg, env.world, env.rank, env.dev
+    gen, seed, per_gpu, chunk, desc = WORKLOADS[name]
+    if per_gpu_override:
+        per_gpu = per_gpu_override
+    if chunk_override:
+        chunk = chunk_override
     per_gpu = (per_gpu // chunk) * chunk or chunk
     k_local = per_gpu // chunk
     k_total = k_local * world
     start = rank * per_gpu  # this rank's contiguous span of the stream
 
-    svc = pkg.HipCompressionService(chunk_size_mb=max(1, chunk >> 20), device=local_rank)
+    svc = pkg.HipCompressionService(chunk_size_mb=max(1, chunk >> 20), device=env.local_rank)
     lib, h = pkg.lib(), svc.ctx.handle
     t_in = torch.empty(per_gpu, dtype=torch.uint8, device=dev)
     fill = {"java_random": lambda: lib.dczu_fill_java_random(h, t_in.data_ptr(), per_gpu, seed, start, None),
@@ -115,22 +111,22 @@ def main():
     def step():
         svc.compress_device(t_in, chunk, out=blk)
         if world > 1:  # the one real exchange step: per-chunk compressed sizes -> global payload offsets
-            sharding.gather_chunk_sizes(blk.comp_size, k_total)
+            env.sharding.gather_chunk_sizes(blk.comp_size, k_total)
         svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, chunk, t_out=t_out,
                               status=dstatus, errpos=derrpos)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
 
     verified = None
-    if not args.no_verify:
+    if verify:
         step()
         torch.cuda.synchronize(dev)
         verified = bool(int(blk.status.abs().sum().item()) == 0 and int(dstatus.abs().sum().item()) == 0
                         and torch.equal(t_out, t_in))
         if not verified:
-            raise SystemExit("round trip is not bit-exact on rank %d" % rank)
+            raise SystemExit("round trip of %s is not bit-exact on rank %d" % (name, rank))
 
     svc.ctx.reset_profiling()
     svc.ctx.set_profiling(True)  # hipEvents around every kernel, on the stream the kernels run on
@@ -138,7 +134,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):  # all steps are queued back to back: nothing in the loop waits for the device
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -147,86 +143,19 @@ def main():
     svc.ctx.set_profiling(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if env.args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     comp_bytes = int(blk.total.item())
     kern = {}
-    for kid, name in pkg.native.KERNEL_NAMES.items():
+    for kid, kname in pkg.native.KERNEL_NAMES.items():
         ms, launches = svc.ctx.kernel_time(kid)
-        kern[name] = {"ms_total": ms, "launches": launches, "avg_ms": (ms / launches) if launches else 0.0}
-    # algorithmic bytes per STEP; a kernel may be launched more than once per step (the compress call is pipelined
-    # in two halves), so per-launch bytes = per-step bytes * steps / launches
-    alg_bytes = {"k1_histogram": per_gpu, "k3_encode": per_gpu + comp_bytes, "k4_decode": comp_bytes + per_gpu}
-    # K1 fused with the identity copy (include/dcz.h DCZ_K_HISTOGRAM_COPY: every block's payload is its input, stored where
-    # it belongs while it is counted): the encoder then moves N in + C out instead of 2N in + C out, K3 has nothing to move
-    fused = kern["k1_histogram_copy"]["launches"] > 0 and kern["k1_histogram"]["launches"] == 0
-    if fused:
-        alg_bytes = {"k1_histogram_copy": per_gpu + comp_bytes, "k4_decode": comp_bytes + per_gpu}
-    enc_alg = (per_gpu + comp_bytes) if fused else (2 * per_gpu + comp_bytes)
-    enc_read = per_gpu if fused else 2 * per_gpu
-    for name, nb in alg_bytes.items():
-        k = kern[name]
-        k["ms_per_step"] = k["ms_total"] / args.steps
-        k["alg_bytes_per_launch"] = nb * args.steps // max(1, k["launches"])
-        k["gbps"] = (k["alg_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9) if k["avg_ms"] > 0 else 0.0
-    dominant = max(alg_bytes, key=lambda nm: kern[nm]["ms_total"])
-
+        kern[kname] = {"ms_total": ms, "launches": launches, "avg_ms": (ms / launches) if launches else 0.0}
+    shapes = svc.ctx.launch_shapes()
+    res = None
     if rank == 0:
-        # roofline.traffic: HBM bytes of the dominant kernel family from an OFFLINE rocprofv3 --pmc pass (tools/traffic.sh ->
-        # profiles/pmc_traffic.json); only quoted when that pass ran this very workload shape, otherwise null + the reason
-        traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        try:
-            with open(pmc_path) as f:
-                ent = json.load(f).get(args.workload, {})
-            if (ent.get("bytes_per_gpu"), ent.get("chunk_bytes")) != (per_gpu, chunk):
-                traffic_source = "null: profiles/pmc_traffic.json has no pass for %s at %d bytes, %d-byte chunks" % (
-                    args.workload, per_gpu, chunk)
-            elif ent.get(dominant, {}).get("total") is None:
-                traffic_source = "null: no counters for %s in profiles/pmc_traffic.json" % dominant
-            else:  # the PMC figure is per step; report it per launch like `achieved`
-                traffic = ent[dominant]["total"] * args.steps // max(1, kern[dominant]["launches"])
-                traffic_source = "profiles/pmc_traffic.json (offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, %s)" % (
-                    ent.get("build", "build not recorded"))
-        except Exception as e:
-            traffic_source = "null: %s" % e
-        value = world * per_gpu * args.steps / elapsed / 1e9
-        # encode and decode separately (rank 0's own times).  t_dec = the K4 launches of a step,
-        # t_enc = the rest of the step (K1/K2/K3 overlap on two streams, so their kernel times do not add up).
-        step_ms = 1e3 * elapsed / args.steps
-        t_dec = kern["k4_decode"]["ms_total"] / args.steps
-        t_enc = max(step_ms - t_dec, 1e-9)
-        split = {"t_enc_ms": round(t_enc, 4), "t_dec_ms": round(t_dec, 4),
-                 "enc_alg_gbps": round(enc_alg / (t_enc * 1e-3) / 1e9, 2),
-                 "dec_alg_gbps": round((per_gpu + comp_bytes) / (t_dec * 1e-3) / 1e9, 2) if t_dec > 0 else None,
-                 "enc_read_gbps": round(enc_read / (t_enc * 1e-3) / 1e9, 2),
-                 "enc_read_frac_of_peak": round(enc_read / (t_enc * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                 "encoder": "K1 fused with the identity copy (N in + C out)" if fused else "K1, K2, K3 (2N in + C out)"}
-        line = {
-            "metric": "encode+decode GB/s (input bytes)", "value": round(value, 3), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "name": args.workload, "bytes_per_gpu": per_gpu, "chunk_bytes": chunk,
-                       "chunks_per_gpu": k_local, "compressed_bytes_per_gpu": comp_bytes,
-                       "sharding": "contiguous chunk ranges per rank; all-gather of per-chunk sizes (RCCL)"},
-            "verified_bit_exact_round_trip": verified,
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(kern[dominant]["gbps"], 2),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(kern[dominant]["gbps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "alg_bytes_per_launch": kern[dominant]["alg_bytes_per_launch"],
-                         "avg_launch_ms": round(kern[dominant]["avg_ms"], 4)},
-            "roundtrip_roofline": {"alg_bytes_per_step": enc_alg + per_gpu + comp_bytes,
-                                   "achieved": round(world * (enc_alg + per_gpu + comp_bytes) * args.steps / elapsed / 1e9, 2),
-                                   "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                                   "frac": round((enc_alg + per_gpu + comp_bytes) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS, 4)},
-            "split": split,
-            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                        for k, v in kern.items()},
-        }
+        res = _account(env, name, desc, steps, warmup, per_gpu, chunk, k_local, comp_bytes, elapsed, kern, shapes, verified)
         # K5 beside the codec: per-chunk SHA-256 of the resident input, one lane per chunk.
         # Not part of `value` (8(d) excludes CHECKSUM_* stages).
         svc.sha256_device(t_in, chunk)
@@ -235,15 +164,156 @@ def main():
         for _ in range(2):
             svc.sha256_device(t_in, chunk)
         torch.cuda.synchronize(dev)
-        line["sha256_per_chunk"] = {"gbps": round(2 * per_gpu / (time.perf_counter() - ts) / 1e9, 2), "chunks": k_local,
-                                    "note": "one lane per chunk; throughput scales with the number of chunks"}
-        if world == 1 and args.cpu_sample_mib != 0:
-            line["cpu_baseline"] = cpu_baseline(np, args.workload, gen, seed, chunk, args.cpu_sample_mib)
+        res["sha256_per_chunk"] = {"gbps": round(2 * per_gpu / (time.perf_counter() - ts) / 1e9, 2), "chunks": k_local,
+                                   "note": "one lane per chunk; throughput scales with the number of chunks"}
+    svc.close()
+    del t_in, t_out, blk
+    torch.cuda.empty_cache()
+    return res
+
+
+def _account(env, name, desc, steps, warmup, per_gpu, chunk, k_local, comp_bytes, elapsed, kern, shapes, verified):
+    """Algorithmic bytes PER LAUNCH (K1 N read, K3 N read + C written, K4 C read + N written) from the
+    bytes a launch really covers: a compress call runs as one launch of each kernel, or as two pipelined halves
+    (>= 2048 chunks) -- read off K2, which launches once per range whatever else happens.  K1 exists in two variants
+    (include/dcz.h DCZ_K_HISTOGRAM_COPY: it also stores the payload of identity blocks, N read + C written, and K3 then
+    has nothing to move); a run in which both ran is flagged `mixed_launch_shapes` and K3 gets no figure."""
+    world = env.world
+    N, Cb = per_gpu, comp_bytes
+    calls = steps
+    lpc = max(1, round(kern["k2_codebuild"]["launches"] / calls))  # launches per compress call (1, or 2 halves)
+    n_k1, n_k1c = kern["k1_histogram"]["launches"], kern["k1_histogram_copy"]["launches"]
+    fused_frac = n_k1c / max(1, n_k1 + n_k1c)
+    mixed = 0 < n_k1c and 0 < n_k1
+    per_launch = {"k1_histogram": N / lpc if n_k1 else None,
+                  "k1_histogram_copy": (N + Cb) / lpc if n_k1c else None,
+                  "k3_encode": (N + Cb) / lpc if n_k1c == 0 else None,
+                  "k4_decode": float(Cb + N)}
+    for kname, nb in per_launch.items():
+        k = kern[kname]
+        k["ms_per_step"] = k["ms_total"] / steps
+        if nb is None or not k["launches"] or k["avg_ms"] <= 0:
+            k["alg_bytes_per_launch"], k["gbps"] = None, None
+            continue
+        k["alg_bytes_per_launch"] = int(nb)
+        k["gbps"] = nb / (k["avg_ms"] * 1e-3) / 1e9
+        if k["gbps"] > HBM_PEAK_GBPS:  # an accounting error, never a result
+            raise SystemExit("bench.py accounting error: %s at %.0f GB/s exceeds the HBM peak (%d launches, %.4f ms avg)"
+                             % (kname, k["gbps"], k["launches"], k["avg_ms"]))
+    cand = [kn for kn in per_launch if kern[kn]["gbps"] is not None]
+    dominant = max(cand, key=lambda nm: kern[nm]["ms_total"])
+    enc_alg = fused_frac * (N + Cb) + (1 - fused_frac) * (2 * N + Cb)
+    enc_read = fused_frac * N + (1 - fused_frac) * 2 * N
+
+    # roofline.traffic: HBM bytes of the dominant kernel family from an OFFLINE rocprofv3 --pmc pass (tools/traffic.sh ->
+    # profiles/pmc_traffic.json); quoted only when that pass ran this workload shape WITH THE SAME LAUNCH MIX (launches of
+    # every kernel family per step), otherwise null + the reason
+    traffic, traffic_source = None, None
+    lps = {kn: kern[kn]["launches"] / steps for kn in kern}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(name, {})
+        want = ent.get("launches_per_step")
+        if (ent.get("bytes_per_gpu"), ent.get("chunk_bytes")) != (per_gpu, chunk):
+            traffic_source = "null: profiles/pmc_traffic.json has no pass for %s at %d bytes, %d-byte chunks" % (
+                name, per_gpu, chunk)
+        elif want is None or any(abs(want.get(kn, 0) - lps[kn]) > 1e-9 for kn in lps):
+            traffic_source = "null: the PMC pass ran another launch mix (%s) than this run (%s)" % (want, lps)
+        elif ent.get(dominant, {}).get("total") is None:
+            traffic_source = "null: no counters for %s in profiles/pmc_traffic.json" % dominant
+        else:  # the PMC figure is per step; report it per launch like `achieved`
+            traffic = int(ent[dominant]["total"] / max(1e-9, lps[dominant]))
+            traffic_source = "profiles/pmc_traffic.json (offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, %s)" % (
+                ent.get("build", "build not recorded"))
+    except Exception as e:
+        traffic_source = "null: %s" % e
+    value = world * per_gpu * steps / elapsed / 1e9
+    # SURVEY.md 8(d): encode and decode separately (rank 0's own times).  t_dec = the K4 launches of a step,
+    # t_enc = the rest of the step (K1/K2/K3 overlap on two streams, so their kernel times do not add up).
+    step_ms = 1e3 * elapsed / steps
+    t_dec = kern["k4_decode"]["ms_total"] / steps
+    t_enc = max(step_ms - t_dec, 1e-9)
+    split = {"t_enc_ms": round(t_enc, 4), "t_dec_ms": round(t_dec, 4),
+             "enc_alg_gbps": round(enc_alg / (t_enc * 1e-3) / 1e9, 2),
+             "dec_alg_gbps": round((per_gpu + comp_bytes) / (t_dec * 1e-3) / 1e9, 2) if t_dec > 0 else None,
+             "enc_read_gbps": round(enc_read / (t_enc * 1e-3) / 1e9, 2),
+             "enc_read_frac_of_peak": round(enc_read / (t_enc * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "encoder": ("mixed launch shapes: %.0f%% of the K1 launches fused with the identity copy" % (100 * fused_frac)) if mixed
+             else "K1 fused with the identity copy (N in + C out)" if n_k1c else "K1, K2, K3 (2N in + C out)"}
+    rt_alg = enc_alg + per_gpu + comp_bytes
+    return {
+        "value": round(value, 3), "unit": "GB/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(step_ms, 4),
+        "config": {"workload": desc, "name": name, "bytes_per_gpu": per_gpu, "chunk_bytes": chunk,
+                   "chunks_per_gpu": k_local, "compressed_bytes_per_gpu": comp_bytes,
+                   "sharding": "contiguous chunk ranges per rank; all-gather of per-chunk sizes (RCCL)"},
+        "verified_bit_exact_round_trip": verified,
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(kern[dominant]["gbps"], 2),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(kern[dominant]["gbps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     "alg_bytes_per_launch": kern[dominant]["alg_bytes_per_launch"],
+                     "avg_launch_ms": round(kern[dominant]["avg_ms"], 4)},
+        "roundtrip_roofline": {"alg_bytes_per_step": int(rt_alg),
+                               "achieved": round(world * rt_alg * steps / elapsed / 1e9, 2),
+                               "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                               "frac": round(rt_alg * steps / elapsed / 1e9 / HBM_PEAK_GBPS, 4)},
+        "split": split,
+        "launch_shapes": shapes, "mixed_launch_shapes": bool(mixed),
+        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                    for k, v in kern.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="random8g", choices=sorted(WORKLOADS))
+    ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the workload's per-GPU bytes")
+    ap.add_argument("--chunk-bytes", type=int, default=0)
+    ap.add_argument("--cpu-sample-mib", type=int, default=-1,
+                    help="MiB of the stream the CPU oracle is timed on; -1 = auto (10-30 s of CPU work), 0 = off")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="only the headline workload (profiling passes; the default run also times the other configs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only exists "
+                         "to rehearse the N>1 code path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    args = ap.parse_args()
+    env = Env(args)
+
+    head = run_workload(env, args.workload, args.steps, args.warmup, not args.no_verify, args.bytes_per_gpu,
+                        args.chunk_bytes)
+    secondary = {}
+    if not args.no_secondary and not args.bytes_per_gpu and not args.chunk_bytes:
+        for name, st, wu in (SECONDARY_1GPU if env.world == 1 else SECONDARY_NGPU):
+            if name == args.workload:
+                continue
+            r = run_workload(env, name, st, wu, not args.no_verify)
+            if env.rank == 0:
+                secondary[name] = r
+
+    if env.rank == 0:
+        line = {"metric": "encode+decode GB/s (input bytes)", "value": head["value"], "unit": "GB/s",
+                "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+        for k in ("config", "verified_bit_exact_round_trip", "roofline", "roundtrip_roofline", "split", "launch_shapes",
+                  "mixed_launch_shapes", "kernels", "sha256_per_chunk"):
+            line[k] = head[k]
+        if secondary:
+            line["secondary"] = secondary
+        if env.world == 1 and args.cpu_sample_mib != 0:
+            gen, seed, _, chunk, _ = WORKLOADS[args.workload]
+            line["cpu_baseline"] = cpu_baseline(env.np, args.workload, gen, seed, args.chunk_bytes or chunk,
+                                                args.cpu_sample_mib)
         print(json.dumps(line), flush=True)
 
-    svc.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if env.world > 1:
+        env.dist.destroy_process_group()
 
 
 def cpu_baseline(np, workload, gen, seed, chunk, sample_mib):

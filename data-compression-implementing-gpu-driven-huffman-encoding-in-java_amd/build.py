@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libdczhip.so")
-SOURCES = ["dcz_api.hip", "k1_histogram.hip", "k2_codebuild.hip", "k3_encode.hip", "k4_decode.hip", "k4_fixed.hip", "k4_regwin.hip", "k4_split.hip", "k4_dfa.hip", "k5_sha256.hip", "gen.hip"]
+SOURCES = ["dcz_api.hip", "k1_histogram.hip", "k2_codebuild.hip", "k3_encode.hip", "k4_decode.hip", "k4_fixed.hip", "k4_split.hip", "k4_dfa.hip", "k5_sha256.hip", "gen.hip"]
 HEADERS = ["dcz_internal.h", os.path.join("..", "..", "include", "dcz.h")]
 
 

@@ -36,24 +36,36 @@ struct dcz_ctx {
     uint8_t* st_meta = nullptr;  // 8 KiB of small per-block device fields
     uint8_t* st_batch = nullptr;  // per-chunk device columns of the host-pointer batch API (grow-only)
     size_t st_batch_K = 0;
-    // launch-shape hints (ShapeHint, dcz_internal.h): host-mapped words [0] decode, [1] encode = sequence number of the
-    // last call whose classification met a block for k4_fixed / k3_copy_identity; read without synchronising
+    // launch-shape hints (ShapeHint, dcz_internal.h), host-mapped words written by the classification kernels and read
+    // without synchronising: [0] last decode call that met a block for k4_fixed, [3] last decode call classified;
+    // [1] last encode call with an identity block, [2] last encode call with a block of any other kind.
+    // Every word is a COMPLETED call's sequence number; the decision compares them with each other, so it does not
+    // depend on how many calls the host has queued (round 2 compared with the issued count: every call after the 8th
+    // queued one got the fallback shape).
     volatile uint32_t* hint_host = nullptr;
     uint32_t* hint_dev = nullptr;
     uint32_t epoch[2] = {0, 0};
+    uint64_t shapes[4] = {0, 0, 0, 0};  // dcz_ctx_launch_shapes
+    static constexpr uint32_t HINT_WINDOW = 8;  // completed calls a sighting stays in force
     ShapeHint next_hint(int which) {
         ShapeHint h;
         if (!hint_host) return h;  // (no mapped memory: always the flat grids)
-        h.dev = hint_dev + which;
         h.epoch = ++epoch[which];
-        const uint32_t seen = hint_host[which];
-        // unknown on the first call; afterwards "likely" while a call of the last 8 had such a block
-        h.likely = h.epoch <= 1u || (seen != 0u && seen + 8u >= h.epoch);
-        if (which == 1 && in_place_ok) {
-            // K1 stores the input at the same offsets of the output when the last calls had identity blocks and none
-            // had anything else (word 2: sequence number of the last call with a block of another kind)
-            const uint32_t other = hint_host[2];
-            h.in_place = seen != 0u && seen + 8u >= h.epoch && (other == 0u || other + 8u < h.epoch);
+        if (which == 0) {
+            h.dev = hint_dev + 0;
+            h.done = hint_dev + 3;
+            const uint32_t with = hint_host[0], done = hint_host[3];
+            // nothing completed yet: unknown, take the flat grid
+            h.likely = done == 0u || (with != 0u && with + HINT_WINDOW >= done);
+        } else {
+            h.dev = hint_dev + 1;
+            const uint32_t ident = hint_host[1], other = hint_host[2];
+            const uint32_t done = ident > other ? ident : other;
+            h.likely = done == 0u || (ident != 0u && ident + HINT_WINDOW >= done);
+            // K1 stores the input at the same offsets of the output when the last completed calls had identity blocks
+            // and none of them had anything else
+            h.in_place = in_place_ok && ident != 0u && ident + HINT_WINDOW >= done &&
+                         (other == 0u || other + HINT_WINDOW < done);
         }
         return h;
     }
@@ -392,6 +404,7 @@ int dcz_compress_blocks(dcz_ctx* c, const void* d_in, size_t n, size_t block_byt
     ShapeHint enc_hint = c->next_hint(1);
     // the copy needs room for the whole input at its own offsets, and 16-byte units that are aligned in both buffers
     if (out_cap < n || ((reinterpret_cast<uintptr_t>(in) - reinterpret_cast<uintptr_t>(out)) & 15u) != 0u) enc_hint.in_place = false;
+    c->shapes[(enc_hint.likely && !enc_hint.in_place) ? 2 : 3]++;
     auto k1 = [&](uint32_t k0, uint32_t kn, hipStream_t st) {
         size_t ob, lb;
         uint64_t s0;
@@ -469,6 +482,7 @@ int dcz_decompress_blocks(dcz_ctx* c, const void* d_comp, size_t comp_bytes, con
         KernelTimer t(c, s, DCZ_K_DECODE);
         DecodeWs ws = decode_ws_at(c->dws, c->cap_dws_K);
         ws.fixed = c->next_hint(0);
+        c->shapes[ws.fixed.likely ? 0 : 1]++;
         launch_decode(static_cast<const uint8_t*>(d_comp), comp_bytes, d_comp_off, d_comp_size, d_orig_size, d_len,
                       (uint32_t)K, out_stride, static_cast<uint8_t*>(d_out), d_status, d_errpos, ws, s);
     }
@@ -770,7 +784,14 @@ int dcz_ctx_reset_profiling(dcz_ctx* c) {
         c->ms[i] = 0;
         c->launches[i] = 0;
     }
+    for (auto& v : c->shapes) v = 0;
     return r;
+}
+
+int dcz_ctx_launch_shapes(dcz_ctx* c, uint64_t counts[4]) {
+    if (!c || !counts) return DCZ_E_INVALID;
+    for (int i = 0; i < 4; i++) counts[i] = c->shapes[i];
+    return DCZ_OK;
 }
 
 int dcz_ctx_kernel_time(dcz_ctx* c, int kernel, double* total_ms, uint64_t* launches) {

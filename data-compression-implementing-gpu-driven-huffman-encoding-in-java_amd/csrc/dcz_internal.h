@@ -20,20 +20,23 @@ void launch_histogram(const uint8_t* d_in, size_t n, size_t block_bytes, uint32_
 void launch_sum_hist(const uint16_t* seg_hist, uint64_t nseg, int64_t* d_hist, hipStream_t s);
 
 // Launch-shape hint.  Two kernels serve blocks that most inputs do not have (k4_fixed: fixed-length complete codes,
-// k3_copy_identity: 256 symbols of 8 bits) with a flat grid of one workgroup per 16 KiB tile of EVERY block, because that
-// is what copies fastest; on inputs without such blocks those grids cost 0.06-0.11 ms per 8 GiB for nothing.  The
-// classification (k4_classify, k2_codebuild) stores the call's sequence number into a host-mapped word whenever it meets
-// such a block; the host reads the word -- without synchronising, so it reflects calls that have completed -- and gives
-// the kernels a small persistent grid instead when none was seen in the last calls.  Both shapes are correct for any
-// input; the hint only chooses the cheaper one.
+// k3_copy_identity: 256 symbols of 8 bits) with a flat grid of one workgroup per tile of EVERY block, because that is what
+// copies fastest; on inputs without such blocks those grids cost 0.06-0.11 ms per 8 GiB for nothing.  The classification
+// kernels (k4_classify, k2_codebuild) publish what they met in host-mapped words: the sequence number of the last call
+// that had such a block, and the sequence number of the last call that was classified at all.  The host reads the words
+// without synchronising and compares them WITH EACH OTHER, never with the number of calls it has issued: the words only
+// move when a call completes, so the decision is "what the last completed calls looked like" however many calls are
+// queued behind them (no news = same as before).  Both shapes are correct for any input and the persistent shape still
+// spreads its work over the whole grid; the hint only chooses the cheaper one.
 struct ShapeHint {
-    uint32_t* dev = nullptr;  // device address of the word (nullptr: nothing is recorded)
-    uint32_t epoch = 0;       // this call's sequence number (> 0)
-    bool likely = true;       // flat grid
-    // Encoder only.  dev[1] (the word after dev's) receives the sequence number of calls that had a block WITHOUT the
-    // identity code.  `in_place`: K1 copied the input to the output at the same offsets (launch_histogram's copy_out) because
-    // the calls before had nothing but identity blocks; k3_copy_identity then leaves alone every identity block whose payload
-    // offset equals its input offset.
+    uint32_t* dev = nullptr;   // device address of the "had such a block" word (nullptr: nothing is recorded)
+    uint32_t* done = nullptr;  // decoder: device address of the "classified" word.  The encoder needs none: every block
+                               // of k2_codebuild stores into dev[0] (identity code) or dev[1] (any other code)
+    uint32_t epoch = 0;        // this call's sequence number (> 0)
+    bool likely = true;        // flat grid
+    // Encoder only.  `in_place`: K1 copied the input to the output at the same offsets (launch_histogram's copy_out)
+    // because the last completed calls had nothing but identity blocks; k3_copy_identity then leaves alone every identity
+    // block whose payload offset equals its input offset.
     bool in_place = false;
     unsigned long long in_offset = 0;  // byte offset, inside the call's input, of the block range a launch covers
 };
@@ -136,11 +139,6 @@ void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, cons
 void launch_split_count(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                         const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, uint8_t* d_cls, int32_t* d_status,
                         int64_t* d_errpos, const SplitDesc& sd, SplitDesc* d_sd, hipStream_t s);
-// k4_regwin.hip: table walk for the medium class (register window, multi-symbol tables)
-void launch_decode_regwin(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
-                          const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,
-                          int32_t* d_status, int64_t* d_errpos, const DecodeWs& ws, bool few_blocks, hipStream_t s);
-
 // k4_dfa.hip: nibble automaton for the medium class (one workgroup per block)
 void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,
                        const uint32_t* d_orig_size, const uint8_t* d_len, uint32_t K, size_t out_stride, uint8_t* d_out,

@@ -1,7 +1,10 @@
 // dcz_cli.cpp -- command line with the surface of cli/DataCompCLI.java:24-146:
 //   dczcli compress|c|decompress|d <input> <output> [chunkMB] [--gpus N]   (default chunk 32 MB, DataCompCLI.java:35)
-// plus `verify <file.dcz>`, `histogram <file>`, `bench <file> [chunkMB] [--gpus N]` (benchmark/BenchmarkSuite.java:68-121:
-// 3 warm-ups, 5 timed runs, MB/s = bytes / 1e6 / s, for compress AND decompress, with the StageMetrics summary) and
+// plus `verify <file.dcz>`, `histogram <file>`, `bench <file> [chunkMB] [--gpus N] [--cpu-mbps X]`
+// (benchmark/BenchmarkSuite.java:37-121: 3 warm-ups, 5 timed runs, MB/s = bytes / 1e6 / s, for compress AND decompress,
+// the StageMetrics summary, a byte-for-byte check of the round trip, and BenchmarkComparison's summary: the CPU line and
+// "GPU Speedup" need a CPU figure, which this product cannot produce -- it holds no CPU codec -- so it is handed in:
+// --cpu-mbps = MB/s of the reference's CpuCompressionService on the same file, or of bench.py's cpu_baseline) and
 // `shardplan <chunks> <gpus>` (the chunk ranges --gpus N gives each device; needs no GPU).
 // --gpus N shards the file's chunks over N devices of the node (contiguous ranges, one pipeline per device).  The reference CLI is hard-wired to the CPU service
 // (DataCompCLI.java:62); this one runs the HIP service and fails loudly when no gfx950 device is present.
@@ -22,7 +25,7 @@ static void usage() {
     std::fprintf(stderr,
                  "Usage: dczcli <operation> <input> <output> [chunkMB] [--gpus N]\n"
                  "  operations: compress | c | decompress | d | verify <file> | histogram <file>\n"
-                 "              bench <file> [chunkMB] [--gpus N] | shardplan <chunks> <gpus>\n");
+                 "              bench <file> [chunkMB] [--gpus N] [--cpu-mbps X] | shardplan <chunks> <gpus>\n");
 }
 
 static std::string fmt_size(long long b) {
@@ -40,7 +43,20 @@ static long long file_size(const std::string& p) {
 }
 
 // benchmark/BenchmarkSuite.java:68-121 (benchmarkService) for this service, plus the decompress timing upstream lacks
-static int run_bench(const std::string& in, int chunkMB, int gpus) {
+static bool same_bytes(const std::string& a, const std::string& b) {
+    std::ifstream fa(a, std::ios::binary), fb(b, std::ios::binary);
+    if (!fa || !fb) return false;
+    std::vector<char> ba(1 << 20), bb(1 << 20);
+    while (true) {
+        fa.read(ba.data(), (std::streamsize)ba.size());
+        fb.read(bb.data(), (std::streamsize)bb.size());
+        if (fa.gcount() != fb.gcount()) return false;
+        if (fa.gcount() == 0) return true;
+        if (std::memcmp(ba.data(), bb.data(), (size_t)fa.gcount()) != 0) return false;
+    }
+}
+
+static int run_bench(const std::string& in, int chunkMB, int gpus, double cpuMBps) {
     const long long inSize = file_size(in);
     if (inSize < 0) {
         std::fprintf(stderr, "Error: Input file does not exist: %s\n", in.c_str());
@@ -75,14 +91,21 @@ static int run_bench(const std::string& in, int chunkMB, int gpus) {
         decomp();
         dt += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    const bool same = file_size(back) == inSize;
+    const bool same = file_size(back) == inSize && same_bytes(in, back);
     ct /= iters;
     dt /= iters;
     std::printf("Benchmark complete:\n  input %lld bytes, output %lld bytes (ratio %.2f%%), %d iterations after %d warm-ups\n"
                 "  compress:   %.3f s avg, %.2f MB/s\n  decompress: %.3f s avg, %.2f MB/s%s\n",
                 inSize, outSize, inSize ? 100.0 * outSize / inSize : 0.0, iters, warmup, ct, ct > 0 ? inSize / 1e6 / ct : 0.0, dt,
-                dt > 0 ? inSize / 1e6 / dt : 0.0, same ? "" : "  (SIZE MISMATCH after the round trip)");
+                dt > 0 ? inSize / 1e6 / dt : 0.0, same ? "  (round trip byte-identical)" : "  (ROUND TRIP DIFFERS FROM THE INPUT)");
     std::printf("\n[compress] %s\n[decompress] %s", cm.summary().c_str(), dm.summary().c_str());
+    // BenchmarkSuite.BenchmarkComparison.getSummary (benchmark/BenchmarkSuite.java:152-170), compress throughput
+    const double mbps = ct > 0 ? inSize / 1e6 / ct : 0.0;
+    std::printf("\n=== Benchmark Results ===\n");
+    if (cpuMBps > 0) std::printf("CPU (figure handed in with --cpu-mbps): %.2f MB/s (%.3fs)\n", cpuMBps, inSize / 1e6 / cpuMBps);
+    std::printf("%s: %.2f MB/s (%.3fs)\n", svc.getServiceName().c_str(), mbps, ct);
+    if (cpuMBps > 0) std::printf("GPU Speedup: %.2fx\n", mbps / cpuMBps);
+    else std::printf("CPU leg: none in this product (no CPU codec); pass --cpu-mbps, or see bench.py's cpu_baseline\n");
     std::remove(dcz.c_str());
     std::remove(back.c_str());
     return same ? 0 : 2;
@@ -91,8 +114,13 @@ static int run_bench(const std::string& in, int chunkMB, int gpus) {
 int main(int argc, char** argv) {
     // --gpus N anywhere on the line
     int gpus = 0;
+    double cpuMBps = 0;
     std::vector<char*> av;
     for (int i = 0; i < argc; i++) {
+        if (std::strcmp(argv[i], "--cpu-mbps") == 0 && i + 1 < argc) {
+            cpuMBps = std::atof(argv[++i]);
+            continue;
+        }
         if (std::strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) {
             gpus = std::atoi(argv[++i]);
             if (gpus < 1) {
@@ -127,7 +155,7 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "Invalid chunk size: %s\n", argv[3]);
                 return 1;
             }
-            return run_bench(in, chunkMB, gpus);
+            return run_bench(in, chunkMB, gpus, cpuMBps);
         }
         if (op == "verify") {
             datacomp::HipCompressionService svc(32);

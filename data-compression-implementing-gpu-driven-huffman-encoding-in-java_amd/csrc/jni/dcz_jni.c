@@ -146,7 +146,7 @@ JNIEXPORT jlong JNICALL Java_com_datacomp_service_hip_HipNative_compressBlocks(
         return DCZ_E_INVALID;
     if (K == 0) return 0;
     /* small host columns: one allocation */
-    uint8_t* cols = (uint8_t*)malloc((size_t)K * (8 + 4 + 4 + 256 + 32));
+    uint8_t* cols = (uint8_t*)calloc((size_t)K, 8 + 4 + 4 + 256 + 32);  /* cleared: an early failure must not hand heap bytes to Java */
     if (!cols) return DCZ_E_HIP;
     uint64_t* c_off = (uint64_t*)cols;
     uint32_t* c_size = (uint32_t*)(cols + 8 * K);

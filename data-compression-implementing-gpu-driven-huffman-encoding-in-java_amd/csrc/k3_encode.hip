@@ -460,18 +460,41 @@ __global__ __launch_bounds__(CP_T) void k3_copy_identity(const uint8_t* __restri
         copy_identity_item(bq, blockIdx.x - bq * tiles_per_block, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out,
                            in_place, in_offset);
     } else {
-        // CP_T blocks at a time: all threads look at one flag each, and a range without a flagged block is skipped whole
+        // CP_T blocks at a time: every thread looks at one flag, the flagged blocks are compacted in block order (every
+        // workgroup builds the same list) and the (flagged block, tile) pairs of the range are dealt round-robin over the
+        // whole grid -- a wrong expectation must not leave most of the chip idle (see k4_fixed<true>)
+        __shared__ uint16_t flagged[CP_T];
+        __shared__ uint32_t fcnt[CP_T / 64];
+        const uint32_t tid = threadIdx.x, w = tid >> 6;
+        uint32_t rot = 0;
         for (uint32_t c0 = 0; c0 < nblk; c0 += (uint32_t)CP_T) {
-            const uint32_t bi = c0 + threadIdx.x;
-            const int mine = bi < nblk && (d_maxlen[b0 + bi] & 0x80u) != 0u &&
-                             !(in_place && d_comp_off[b0 + bi] == in_offset + (unsigned long long)(b0 + bi) * block_bytes);
-            if (!__syncthreads_or(mine)) continue;  // workgroup-uniform
-            const uint32_t c1 = (nblk - c0 < (uint32_t)CP_T) ? nblk : c0 + (uint32_t)CP_T;
-            for (uint32_t bq = c0; bq < c1; bq++) {
-                if ((d_maxlen[b0 + bq] & 0x80u) == 0u) continue;
-                for (uint32_t tile = blockIdx.x; tile < tiles_per_block; tile += gridDim.x)
-                    copy_identity_item(bq, tile, in, n, block_bytes, b0, d_maxlen, d_comp_off, d_status, out, in_place, in_offset);
+            const uint32_t bi = c0 + tid;
+            const bool mine = bi < nblk && (d_maxlen[b0 + bi] & 0x80u) != 0u &&
+                              !(in_place && d_comp_off[b0 + bi] == in_offset + (unsigned long long)(b0 + bi) * block_bytes);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if ((tid & 63u) == 0u) fcnt[w] = (uint32_t)__builtin_popcountll(m);
+            __syncthreads();
+            uint32_t base = 0, nflag = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)(CP_T / 64); i++) {
+                base += i < w ? fcnt[i] : 0u;
+                nflag += fcnt[i];
             }
+            if (nflag == 0u) {  // workgroup-uniform
+                __syncthreads();
+                continue;
+            }
+            if (mine) flagged[base + (uint32_t)__builtin_popcountll(m & ((1ull << (tid & 63u)) - 1ull))] = (uint16_t)tid;
+            __syncthreads();
+            const unsigned long long items = (unsigned long long)nflag * tiles_per_block;
+            const uint32_t first = (blockIdx.x + gridDim.x - rot) % gridDim.x;
+            for (unsigned long long it = first; it < items; it += gridDim.x) {
+                const uint32_t f = (uint32_t)(it / tiles_per_block);
+                copy_identity_item(c0 + flagged[f], (uint32_t)(it - (unsigned long long)f * tiles_per_block), in, n, block_bytes,
+                                   b0, d_maxlen, d_comp_off, d_status, out, in_place, in_offset);
+            }
+            rot = (uint32_t)((rot + items) % gridDim.x);
+            __syncthreads();  // (flagged / fcnt are rewritten by the next range)
         }
     }
 }

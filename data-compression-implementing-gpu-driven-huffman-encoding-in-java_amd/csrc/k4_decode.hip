@@ -1298,28 +1298,14 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
             DCZ_K4_LAUNCH_G(grid, ws.sdesc, DCZ_K4_W, 1, DCZ_K4L_OC, 0, true, 1, DCZ_K4_TBS, 3);
         }
     }
-    // DCZ_K4_MEDIUM_REGWIN=1 decodes the medium class (3.6 .. 6.5 bits per symbol) with k4_regwin.hip (register-window
-    // multi-symbol walk) instead of the parked table walk.  Measured on 8 GiB of text: 16.3 ms against 14.4 ms (it issues
-    // fewer LDS operations but more vector instructions, and both kernels are issue-bound), so it is off by default; its
-    // jump walk is what the split decoder's counting pass uses.
-#ifndef DCZ_K4_MEDIUM_REGWIN
-#define DCZ_K4_MEDIUM_REGWIN 0
-#endif
     if (K >= few_below) {
         static_assert(DCZ_K4_W <= 512, "many-blocks kernel");
 #if DCZ_K4_EXACT
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 2);
-#if !DCZ_K4_MEDIUM_REGWIN
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 2);
 #endif
-#endif
         DCZ_K4_LAUNCH(DCZ_K4_W, DCZ_K4_NS, DCZ_K4_OC, DCZ_K4_PRIV, false, 4, DCZ_K4_TB, 0);
-#if DCZ_K4_MEDIUM_REGWIN
-        launch_decode_regwin(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos,
-                             ws, false, s);
-#else
         DCZ_K4_LAUNCH(DCZ_K4_W, 1, DCZ_K4M_OC, DCZ_K4_PRIVM, false, 2, DCZ_K4_TBM, 0);
-#endif
 #if DCZ_K4_MEDIUM_DFA
         launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, 0, s);
 #endif
@@ -1331,17 +1317,10 @@ void launch_decode(const uint8_t* d_comp, size_t comp_bytes, const uint64_t* d_c
     } else {
 #if DCZ_K4_EXACT
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 2);
-#if !DCZ_K4_MEDIUM_REGWIN
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 2);
 #endif
-#endif
         DCZ_K4_LAUNCH(1024, DCZ_K4S_NS, DCZ_K4S_OC, DCZ_K4S_PRIV, false, 4, DCZ_K4_TB, 0);
-#if DCZ_K4_MEDIUM_REGWIN
-        launch_decode_regwin(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos,
-                             ws, true, s);
-#else
         DCZ_K4_LAUNCH(1024, 1, DCZ_K4S_OC, DCZ_K4S_PRIVM, false, 2, DCZ_K4_TBM, 0);
-#endif
 #if DCZ_K4_MEDIUM_DFA
         launch_decode_dfa(d_comp, d_comp_off, d_comp_size, d_orig_size, d_len, K, out_stride, d_out, d_status, d_errpos, ws, 0, s);
 #endif

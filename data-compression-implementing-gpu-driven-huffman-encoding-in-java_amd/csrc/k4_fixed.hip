@@ -47,9 +47,11 @@ __global__ __launch_bounds__(256) void k4_classify(const uint8_t* __restrict__ d
                                                    const uint32_t* __restrict__ d_orig_size, unsigned long long comp_bytes,
                                                    unsigned long long out_stride, uint32_t K, uint8_t* __restrict__ cls,
                                                    int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
-                                                   uint32_t* __restrict__ hint, uint32_t epoch) {
+                                                   uint32_t* __restrict__ hint, uint32_t* __restrict__ hint_done,
+                                                   uint32_t epoch) {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= K) return;
+    if (b == 0u && hint_done) *hint_done = epoch;  // (ShapeHint: this call has been classified)
     const uint4* row = reinterpret_cast<const uint4*>(d_len + (uint64_t)b * 256u);
     uint32_t n = 0, mn = 255u, mx = 0;
 #pragma unroll 4
@@ -229,8 +231,12 @@ __device__ __forceinline__ void fixed_item(FxLds& S, uint32_t b, uint32_t tile, 
     }
 }
 
-// PERSIST = false: flat grid, one workgroup per work item (what copies fastest).  PERSIST = true: a small grid that walks
-// over the work items -- for calls in which no fixed-length block is expected (ShapeHint, dcz_internal.h).
+// PERSIST = false: flat grid, one workgroup per work item (what copies fastest).  PERSIST = true: a small grid that finds
+// the fixed-length blocks itself -- for calls in which none is expected (ShapeHint, dcz_internal.h).  When the
+// expectation was wrong the persistent shape must still use the whole chip: FX_T blocks at a time, every thread looks at
+// one class byte, the flagged blocks are compacted (in block order, so every workgroup builds the same list) and the
+// (flagged block, tile) pairs of the range are dealt round-robin over the grid; `rot` carries the deal across ranges so
+// that remainders do not pile up on the first workgroups.
 template <bool PERSIST>
 __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ comp,
                                                  const unsigned long long* __restrict__ d_comp_off,
@@ -245,20 +251,38 @@ __global__ __launch_bounds__(FX_T) void k4_fixed(const uint8_t* __restrict__ com
         const uint32_t b = wi / tiles_per_block;
         fixed_item(S, b, wi - b * tiles_per_block, comp, d_comp_off, d_comp_size, d_orig_size, d_len, out_stride, out, cls);
     } else {
-        // FX_T blocks at a time: all threads look at one class byte each, and a range without a fixed-length block is
-        // skipped whole
+        __shared__ uint16_t flagged[FX_T];
+        __shared__ uint32_t fcnt[FX_T / 64];
+        const uint32_t tid = threadIdx.x, w = tid >> 6;
+        uint32_t rot = 0;  // items dealt so far, mod gridDim.x
         for (uint32_t c0 = 0; c0 < nblk; c0 += (uint32_t)FX_T) {
-            const uint32_t bi = c0 + threadIdx.x;
-            const int mine = bi < nblk && (cls[bi] & 0xF0u) == 0x10u;
-            if (!__syncthreads_or(mine)) continue;  // workgroup-uniform
-            const uint32_t c1 = (nblk - c0 < (uint32_t)FX_T) ? nblk : c0 + (uint32_t)FX_T;
-            for (uint32_t b = c0; b < c1; b++) {
-                if ((cls[b] & 0xF0u) != 0x10u) continue;
-                for (uint32_t tile = blockIdx.x; tile < tiles_per_block; tile += gridDim.x) {
-                    fixed_item(S, b, tile, comp, d_comp_off, d_comp_size, d_orig_size, d_len, out_stride, out, cls);
-                    __syncthreads();  // (the staging area and the symbol table are reused)
-                }
+            const uint32_t bi = c0 + tid;
+            const bool mine = bi < nblk && (cls[bi] & 0xF0u) == 0x10u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if ((tid & 63u) == 0u) fcnt[w] = (uint32_t)__builtin_popcountll(m);
+            __syncthreads();
+            uint32_t base = 0, nflag = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)(FX_T / 64); i++) {
+                base += i < w ? fcnt[i] : 0u;
+                nflag += fcnt[i];
             }
+            if (nflag == 0u) {  // workgroup-uniform
+                __syncthreads();
+                continue;
+            }
+            if (mine) flagged[base + (uint32_t)__builtin_popcountll(m & ((1ull << (tid & 63u)) - 1ull))] = (uint16_t)tid;
+            __syncthreads();
+            const unsigned long long items = (unsigned long long)nflag * tiles_per_block;
+            const uint32_t first = (blockIdx.x + gridDim.x - rot) % gridDim.x;
+            for (unsigned long long it = first; it < items; it += gridDim.x) {
+                const uint32_t f = (uint32_t)(it / tiles_per_block);
+                fixed_item(S, c0 + flagged[f], (uint32_t)(it - (unsigned long long)f * tiles_per_block), comp, d_comp_off,
+                           d_comp_size, d_orig_size, d_len, out_stride, out, cls);
+                __syncthreads();  // (the staging area and the symbol table are reused)
+            }
+            rot = (uint32_t)((rot + items) % gridDim.x);
+            __syncthreads();  // (flagged / fcnt are rewritten by the next range)
         }
     }
 }
@@ -269,7 +293,7 @@ void launch_classify(const uint8_t* d_len, const uint64_t* d_comp_off, const uin
     hipLaunchKernelGGL(k4_classify, dim3((K + 255) / 256), dim3(256), 0, s, d_len,
                        reinterpret_cast<const unsigned long long*>(d_comp_off), d_comp_size, d_orig_size,
                        (unsigned long long)comp_bytes, (unsigned long long)out_stride, K, ws.cls, d_status,
-                       reinterpret_cast<long long*>(d_errpos), ws.fixed.dev, ws.fixed.epoch);
+                       reinterpret_cast<long long*>(d_errpos), ws.fixed.dev, ws.fixed.done, ws.fixed.epoch);
 }
 
 void launch_decode_fixed(const uint8_t* d_comp, const uint64_t* d_comp_off, const uint32_t* d_comp_size,

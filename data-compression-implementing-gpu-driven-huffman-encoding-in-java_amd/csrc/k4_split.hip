@@ -7,7 +7,7 @@
 // intra-block offsets, so the split is found the way windows are synchronised inside a workgroup, one level up:
 //   pass 1 (k4_split_count): the payload of a block is cut into REGIONS of S bytes (S a multiple of the 8 KiB window, at
 //     least 64 KiB; the size is chosen on the device from the payload bytes the call really has).  The workgroup of region r
-//     first walks the window in front of its region from a guessed entry (the jump walk of k4_regwin.hip: jt[12-bit
+//     first walks the window in front of its region from a guessed entry (a jump walk: jt[12-bit
 //     window] = bits and number of the complete codewords inside it, one codeword at a time in the last 12 bits of a
 //     subsequence); Huffman streams re-synchronise within a few codewords, so the first codeword boundary at or past the
 //     region start that this walk finds is the region's entry with overwhelming probability.  It then walks its region
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SP_W) void k4_split_count(const uint8_t* __restrict
     const unsigned long long nreg = (vhi + S - 1) / S;
     if (nreg < 2 || r >= nreg || nreg > sd.rmax) return;  // a block of one region is not split
 
-    // ---- tables (as in k4_decode.hip / k4_regwin.hip) ----
+    // ---- tables (as in k4_decode.hip) ----
     if (tid < 34) L.cnt[tid] = 0;
     if (tid == 0) {
         L.bad_table = 0;

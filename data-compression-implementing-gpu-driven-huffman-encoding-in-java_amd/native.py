@@ -27,7 +27,7 @@ SYMBOLS = [
     "dcz_histogram", "dcz_build_codes", "dcz_codes_from_lengths", "dcz_encode_block", "dcz_decode_block",
     "dcz_compress_blocks", "dcz_decompress_blocks", "dcz_host_register", "dcz_host_unregister", "dcz_ctx_pinned",
     "dcz_compress_host", "dcz_decompress_host", "dcz_ctx_set_profiling", "dcz_ctx_reset_profiling",
-    "dcz_ctx_kernel_time", "dcz_sha256_blocks", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
+    "dcz_ctx_kernel_time", "dcz_ctx_launch_shapes", "dcz_sha256_blocks", "dczu_fill_java_random", "dczu_fill_text", "dczu_fill_lowentropy",
 ]
 
 _lib = None
@@ -100,6 +100,8 @@ def lib():
     L.dcz_ctx_reset_profiling.restype = i32
     L.dcz_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
     L.dcz_ctx_kernel_time.restype = i32
+    L.dcz_ctx_launch_shapes.argtypes = [vp, C.POINTER(u64 * 4)]
+    L.dcz_ctx_launch_shapes.restype = i32
     L.dcz_sha256_blocks.argtypes = [vp, vp, sz, sz, vp, vp]
     L.dcz_sha256_blocks.restype = i32
     L.dczu_fill_java_random.argtypes = [vp, vp, sz, C.c_int64, u64, vp]
@@ -159,3 +161,9 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         self.check(lib().dcz_ctx_kernel_time(self.handle, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def launch_shapes(self):
+        """-> dict of calls by chosen launch shape since the last reset_profiling (include/dcz.h dcz_ctx_launch_shapes)."""
+        a = (C.c_uint64 * 4)()
+        self.check(lib().dcz_ctx_launch_shapes(self.handle, C.byref(a)))
+        return {"decode_flat": a[0], "decode_persistent": a[1], "encode_flat": a[2], "encode_persistent": a[3]}

@@ -176,6 +176,12 @@ enum {
 int dcz_ctx_set_profiling(dcz_ctx* ctx, int on);
 int dcz_ctx_reset_profiling(dcz_ctx* ctx);
 int dcz_ctx_kernel_time(dcz_ctx* ctx, int kernel, double* total_ms, uint64_t* launches);
+/* Launch shapes chosen since the context was created or dcz_ctx_reset_profiling was called (counted whether or not
+ * profiling is on): counts[0] decode calls that gave k4_fixed its flat grid, [1] the persistent grid; [2] compress calls
+ * that gave k3_copy_identity its flat grid, [3] the persistent grid (which includes every call counted under
+ * DCZ_K_HISTOGRAM_COPY).  The choice follows what the last COMPLETED calls met, never the number of calls queued: a
+ * benchmark loop that queues many calls must see one shape throughout (tests/test_gpu_parity.py asserts it). */
+int dcz_ctx_launch_shapes(dcz_ctx* ctx, uint64_t counts[4]);
 
 /* ---- checksums ------------------------------------------------ */
 

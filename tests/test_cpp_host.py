@@ -162,3 +162,15 @@ def test_cli_bench_mirrors_benchmark_suite(orc, tmp_path):
                    "Stage Performance Breakdown:", "Encoding", "Decoding"):
         assert needle in r.stdout, needle
     assert not (tmp_path / "b.bin.bench.dcz").exists()
+    assert "round trip byte-identical" in r.stdout and "=== Benchmark Results ===" in r.stdout
+    assert "CPU leg: none in this product" in r.stdout
+    # the throughput printed is bytes / 1e6 / seconds of the compress runs (BenchmarkResult.getThroughputMBps)
+    import re
+    m = re.search(r"compress:\s+([0-9.]+) s avg, ([0-9.]+) MB/s", r.stdout)
+    assert m and abs(3.0 / float(m.group(1)) - float(m.group(2))) <= 0.02 * float(m.group(2)) + 0.5
+    # BenchmarkComparison.getSummary with a CPU figure handed in (BenchmarkSuite.java:143-170): speedup = GPU / CPU
+    r = run("bench", src, 1, "--cpu-mbps", "2.5")
+    assert r.returncode == 0, r.stderr
+    g = re.search(r"\): ([0-9.]+) MB/s \([0-9.]+s\)\nGPU Speedup: ([0-9.]+)x", r.stdout)
+    assert g and "CPU (figure handed in with --cpu-mbps): 2.50 MB/s" in r.stdout
+    assert abs(float(g.group(1)) / 2.5 - float(g.group(2))) < 0.02

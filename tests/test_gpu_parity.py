@@ -1370,8 +1370,116 @@ def test_launch_shape_hint_both_shapes_on_both_kinds_of_input(pkg, orc):
     seq = [text] * 2 + [rnd] * 3 + [text] * 10 + [rnd, six, rnd] + [text] * 10 + [six] * 2
     for i, data in enumerate(seq):
         assert_parity(svc, orc, data, 65536)
-        if i % 4 == 3:
-            torch.cuda.synchronize()  # (let some hints arrive, leave others in flight)
+    svc.close()
+
+
+def _queue_pairs(pkg, svc, datas, bb, reps):
+    """Queue reps compress + decompress pairs per input with NO host synchronisation in between (every pair has its
+    own output tensors), then synchronise once -> list of (input, DeviceBlocks, decoded tensor, status)."""
+    torch = _torch()
+    jobs = []
+    # (growing the context's workspace frees the old one, which waits for the device: size it before anything is queued)
+    svc.ctx.check(pkg.lib().dcz_ctx_reserve(svc.ctx.handle, max(d.size for d in datas), bb))
+    for r in range(reps):
+        data = datas[r % len(datas)]
+        t = torch.from_numpy(data).cuda()
+        K = (data.size + bb - 1) // bb
+        orig = torch.tensor([min(bb, data.size - k * bb) for k in range(K)], dtype=torch.int32, device="cuda")
+        out = pkg.DeviceBlocks(torch.empty(data.size + 16, dtype=torch.uint8, device="cuda"),
+                               torch.zeros(K, dtype=torch.int32, device="cuda"), torch.zeros(K, dtype=torch.int64, device="cuda"),
+                               torch.zeros((K, 256), dtype=torch.uint8, device="cuda"),
+                               torch.zeros(K, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                               data.size, bb)
+        jobs.append((data, t, orig, torch.empty(K * bb, dtype=torch.uint8, device="cuda"),
+                     torch.zeros(K, dtype=torch.int32, device="cuda"), torch.zeros(K, dtype=torch.int64, device="cuda"), out))
+    torch.cuda.synchronize()
+    res = []
+    first_done = torch.cuda.Event()
+    torch.cuda._sleep(int(1.5e9))  # hold the device back (~0.6 s) so that every call below is issued before the first one runs
+    for data, t, orig, t_out, st, ep, out in jobs:  # nothing below allocates or waits for the device
+        blk = svc.compress_device(t, bb, out=out)
+        svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb, t_out=t_out, status=st,
+                              errpos=ep)
+        if not res:
+            first_done.record()
+        res.append((data, blk, t_out, st))
+    assert not first_done.query(), "the queue was not deep: the first pair completed while the others were being issued"
+    torch.cuda.synchronize()
+    return res
+
+
+def _check_pairs(orc, res, bb):
+    for data, blk, t_out, st in res:
+        opay, osizes, ooffs, olens = orc.compress_blocks(data, bb)
+        assert (blk.status.cpu().numpy() == 0).all() and (st.cpu().numpy() == 0).all()
+        assert (blk.code_lengths.cpu().numpy().astype(np.int32) == olens).all()
+        assert (blk.comp_size.cpu().numpy().astype(np.uint32) == osizes).all()
+        assert (blk.comp_off.cpu().numpy().astype(np.uint64) == ooffs).all()
+        assert int(blk.total.item()) == opay.size
+        assert (blk.payload[: opay.size].cpu().numpy() == opay).all(), "payload differs from the oracle"
+        assert (t_out[: data.size].cpu().numpy() == data).all(), "round trip differs"
+
+
+def test_queued_calls_keep_the_launch_shape_of_the_last_completed_calls(pkg, orc):
+    """The back-to-back call pattern of benchmark/BenchmarkSuite.java:77-101 (and of bench.py's timed loop): many calls
+    queued with no host synchronisation.  The launch shapes must follow what the last COMPLETED calls met, however deep
+    the queue is -- round 2 compared with the number of calls ISSUED, and every call after the 8th queued one fell back to
+    the persistent shapes and the unfused K1 (1409 -> 590 GB/s under the driver's 20-step loop)."""
+    torch = _torch()
+    svc = pkg.HipCompressionService(1, 0)  # a context of its own: the hint is per context
+    bb, nv = 65536, pkg.native
+    rnd = [orc.java_random_bytes(900 + i, 48 * bb) for i in range(3)]  # every block: 256 symbols of 8 bits
+    text = [orc.gen_text(40 + i, 0, 48 * bb) for i in range(3)]
+    for i in range(10):  # completed all-identity calls: the state bench.py's warm-up leaves behind
+        assert_parity(svc, orc, rnd[i % 3], bb)
+    svc.ctx.reset_profiling()
+    svc.ctx.set_profiling(True)
+    res = _queue_pairs(pkg, svc, rnd, bb, 24)
+    sh = svc.ctx.launch_shapes()
+    assert sh == {"decode_flat": 24, "decode_persistent": 0, "encode_flat": 0, "encode_persistent": 24}, sh
+    assert svc.ctx.kernel_time(nv.K_HISTOGRAM)[1] == 0, "a queued call fell back to the unfused K1"
+    assert svc.ctx.kernel_time(nv.K_HISTOGRAM_COPY)[1] == 24
+    _check_pairs(orc, res, bb)
+    # the other way round: completed text calls, then a deep queue of text calls -> persistent grids throughout
+    for i in range(10):
+        assert_parity(svc, orc, text[i % 3], bb)
+    svc.ctx.reset_profiling()
+    res = _queue_pairs(pkg, svc, text, bb, 24)
+    sh = svc.ctx.launch_shapes()
+    assert sh == {"decode_flat": 0, "decode_persistent": 24, "encode_flat": 0, "encode_persistent": 24}, sh
+    assert svc.ctx.kernel_time(nv.K_HISTOGRAM_COPY)[1] == 0
+    _check_pairs(orc, res, bb)
+    svc.close()
+
+
+def test_a_wrong_launch_shape_still_gives_the_oracles_bytes(pkg, orc):
+    """Completed text calls, then a deep queue of all-identity / fixed-length inputs: every queued call gets the
+    persistent shapes of k4_fixed and k3_copy_identity WITH work for them (more flagged blocks than one range of the
+    compaction holds, several tiles per block, a ragged last block), and the other way round: in-place speculation and
+    flat grids on text."""
+    torch = _torch()
+    svc = pkg.HipCompressionService(1, 0)
+    bb = 32768
+    rng = np.random.default_rng(11)
+    rnd = orc.java_random_bytes(5, 1300 * bb + 777)  # 1300 identity blocks (> 2 ranges of 512) + a ragged one
+    six = (rng.integers(0, 64, size=700 * bb + 5).astype(np.uint8) + 32)  # fixed-length complete code, 6 bits
+    text = orc.gen_text(9, 0, 40 * bb)
+    for i in range(10):
+        assert_parity(svc, orc, text, bb)
+    svc.ctx.reset_profiling()
+    res = _queue_pairs(pkg, svc, [rnd, six], bb, 6)
+    sh = svc.ctx.launch_shapes()
+    assert sh["decode_persistent"] == 6 and sh["encode_persistent"] == 6, sh
+    _check_pairs(orc, res, bb)
+    small = orc.java_random_bytes(6, 64 * bb)
+    for i in range(10):
+        assert_parity(svc, orc, small, bb)
+    svc.ctx.reset_profiling()
+    res = _queue_pairs(pkg, svc, [text, rnd[: 100 * bb], text], bb, 6)
+    sh = svc.ctx.launch_shapes()
+    assert sh["decode_flat"] == 6 and sh["encode_persistent"] == 6, sh  # (in place: speculated, wrong for the text calls)
+    _check_pairs(orc, res, bb)
+    svc.close()
 
 
 def test_identity_blocks_are_stored_in_place_by_the_histogram_pass(pkg, orc):

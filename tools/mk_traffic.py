@@ -10,7 +10,7 @@ build = sys.argv[5] if len(sys.argv) > 5 else ""
 halves = 2 if per_gpu // chunk >= 2048 else 1
 fam = {"k1_histogram": (["k1_histogram<false>"], halves), "k1_histogram_copy": (["k1_histogram<true>"], halves),
        "k3_encode": (["k3_encode", "k3_copy_identity"], halves),
-       "k4_decode": (["k4_decode", "k4_fixed", "k4_classify", "k4_split", "k4_regwin"], 1)}
+       "k4_decode": (["k4_decode", "k4_fixed", "k4_classify", "k4_split"], 1)}
 res = {}
 for k, (frags, per_step) in fam.items():
     res[k] = {}
@@ -30,6 +30,13 @@ try:
 except Exception:
     allw = {}
 res["bytes_per_gpu"], res["chunk_bytes"], res["build"] = per_gpu, chunk, build
+# the launch mix of the pass (launches of every kernel family per step, from the pass's own bench line): bench.py quotes
+# the traffic only for a run with the same mix
+try:
+    line = json.load(open("gpurun_out/trf_%s_FETCH_SIZE.json" % tag))
+    res["launches_per_step"] = {k: v["launches"] / line["steps"] for k, v in line["kernels"].items()}
+except Exception as e:
+    print("no launch mix recorded:", e, file=sys.stderr)
 res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/traffic.sh); HBM bytes per bench "
                 "step summed over the launches of each kernel family; FETCH_SIZE doubled per MI355X_MICROARCH.md")
 allw[workload] = res

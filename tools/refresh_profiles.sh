@@ -9,7 +9,7 @@ cd $R
 # HBM traffic of the default workload first: bench.py quotes it as roofline.traffic when the shapes match
 export TMPDIR=/tmp
 ( cd /tmp; for P in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/trf_${V}_$P -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample-mib 0 --no-verify > /dev/null 2> $R/gpurun_out/trf_${V}_$P.err || echo "pass $P failed"
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/trf_${V}_$P -- python3 $R/bench.py --no-secondary --steps 3 --warmup 1 --cpu-sample-mib 0 --no-verify > $R/gpurun_out/trf_${V}_$P.json 2> $R/gpurun_out/trf_${V}_$P.err || echo "pass $P failed"
   done )
 python3 tools/mk_traffic.py $V random8g 8589934592 1048576 "build $V" > gpurun_out/traffic_json_$V.txt 2>&1 || echo "mk_traffic failed"
 rm -rf gpurun_out/trf_${V}_FETCH_SIZE gpurun_out/trf_${V}_WRITE_SIZE
@@ -18,6 +18,6 @@ bash tools/profile_workload.sh ${V}_text8g --workload text8g
 bash tools/profile_workload.sh ${V}_lowentropy --workload lowentropy
 bash tools/profile_workload.sh ${V}_text32m --workload text_32m
 timeout -k 10 600 python bench.py > gpurun_out/bench_random8g_$V.json 2> gpurun_out/bench_random8g_$V.err || echo "bench default failed"
-for w in random256m text text8g lowentropy text_32m; do timeout -k 10 300 python bench.py --workload $w --cpu-sample-mib 0 > gpurun_out/bench_${w}_$V.json 2>/dev/null || echo "bench $w failed"; done
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --backend gloo --single-device --bytes-per-gpu 2147483648 --cpu-sample-mib 0 > gpurun_out/bench_2rank_$V.json 2> gpurun_out/bench_2rank_$V.err || echo "2rank failed"
+for w in random256m text text8g lowentropy text_32m; do timeout -k 10 300 python bench.py --no-secondary --workload $w --cpu-sample-mib 0 > gpurun_out/bench_${w}_$V.json 2>/dev/null || echo "bench $w failed"; done
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --no-secondary --gpus 2 --backend gloo --single-device --bytes-per-gpu 2147483648 --cpu-sample-mib 0 > gpurun_out/bench_2rank_$V.json 2> gpurun_out/bench_2rank_$V.err || echo "2rank failed"
 python tools/summ.py gpurun_out/bench_random8g_$V.json gpurun_out/bench_random256m_$V.json gpurun_out/bench_text_$V.json gpurun_out/bench_text8g_$V.json gpurun_out/bench_lowentropy_$V.json gpurun_out/bench_text_32m_$V.json
