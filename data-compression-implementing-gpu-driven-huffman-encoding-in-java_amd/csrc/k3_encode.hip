@@ -197,28 +197,29 @@ __device__ __forceinline__ void encode_chunk_packed(EncState& st, const uint32_t
             uint32_t e1 = lut[(s1 << K3_CSHIFT) + col];
             if (!FULL && i0 >= nb) e0 = 0;
             if (!FULL && i1 >= nb) e1 = 0;
-            const uint32_t l1 = e1 & 0xFFu;
-            pc[j] = ((e0 >> 16) << l1) | (e1 >> 16);
-            pl[j] = (e0 & 0xFFu) + l1;
+            // entry = code << 16 | len with len <= 16: a shift takes its amount from the low 5 (6) bits of the register,
+            // and the low 16 bits of a SUM of entries are the sum of the lengths -- no masking until the strings are final
+            pc[j] = ((e0 >> 16) << (e1 & 31u)) | (e1 >> 16);
+            pl[j] = e0 + e1;
         }
         if constexpr (G == 4) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                gs[q] = ((unsigned long long)pc[2 * q] << pl[2 * q + 1]) | (unsigned long long)pc[2 * q + 1];
-                gl[q] = pl[2 * q] + pl[2 * q + 1];
+                gs[q] = ((unsigned long long)pc[2 * q] << (pl[2 * q + 1] & 63u)) | (unsigned long long)pc[2 * q + 1];
+                gl[q] = (pl[2 * q] + pl[2 * q + 1]) & 0xFFFFu;
                 total += gl[q];
             }
         } else {
             uint32_t qc[4], ql[4];  // quads still fit 32 bits
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                qc[q] = (pc[2 * q] << pl[2 * q + 1]) | pc[2 * q + 1];
+                qc[q] = (pc[2 * q] << (pl[2 * q + 1] & 31u)) | pc[2 * q + 1];
                 ql[q] = pl[2 * q] + pl[2 * q + 1];
             }
 #pragma unroll
             for (int o = 0; o < 2; o++) {
-                gs[o] = ((unsigned long long)qc[2 * o] << ql[2 * o + 1]) | (unsigned long long)qc[2 * o + 1];
-                gl[o] = ql[2 * o] + ql[2 * o + 1];
+                gs[o] = ((unsigned long long)qc[2 * o] << (ql[2 * o + 1] & 63u)) | (unsigned long long)qc[2 * o + 1];
+                gl[o] = (ql[2 * o] + ql[2 * o + 1]) & 0xFFFFu;
                 total += gl[o];
             }
         }

@@ -50,8 +50,18 @@ namespace dcz {
     do {                                                         \
         if constexpr ((j >> 3) >= HOIST_DW) asm volatile("" : "+v"(r)); \
     } while (0)
+// the walks a recording instantiation only falls back to (count, output) extract every nibble where it is used: they must
+// not stretch the live ranges of the walks that count (a COPY is made opaque: the subsequence registers stay loop-invariant)
+#define DFA_FRESH_COPY(dst, r)                                    \
+    uint32_t dst = (r);                                           \
+    do {                                                          \
+        if constexpr (RECORD) asm volatile("" : "+v"(dst));       \
+    } while (0)
 #ifndef DCZ_DFA_HOIST_DW_SPLIT
 #define DCZ_DFA_HOIST_DW_SPLIT 3
+#endif
+#ifndef DCZ_DFA_HOIST_DW_REC
+#define DCZ_DFA_HOIST_DW_REC 7  // (8 spills three registers at four waves per SIMD)
 #endif
 #ifndef DCZ_DFA_HOIST_DW_1024
 #define DCZ_DFA_HOIST_DW_1024 5
@@ -70,9 +80,13 @@ namespace dcz {
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
+#ifndef DCZ_DFA_RECORD
+#define DCZ_DFA_RECORD 1  // 1: two walks per subsequence (exit-only, then ONE walk that counts AND records the symbols in a
+#endif                    // private LDS slot; the slots are closed up in place); 0: three walks (exit-only, count, output)
 #ifndef DCZ_DFA_MINWAVES
-#define DCZ_DFA_MINWAVES 4
+#define DCZ_DFA_MINWAVES 4  // waves per SIMD the 256-thread instantiations are compiled for
 #endif
+#define DFA_OC_DECODE (DCZ_DFA_RECORD ? -1 : DCZ_DFA_OC)  // tile parameter of the decoding instantiations (-1: slot area)
 #ifndef DCZ_K4_EXACT_AFTER
 #define DCZ_K4_EXACT_AFTER 12
 #endif
@@ -85,19 +99,43 @@ namespace dcz {
 
 constexpr uint32_t DFA_ERR = 255;  // sticky state: the stream left the code tree
 
+// Recording walk (DCZ_DFA_RECORD).  Three walks per subsequence (exit-only, count, output) are two when the walk that counts
+// also RECORDS the symbols: every lane has a private slot in LDS, and after the scan the slots are closed up in place (the
+// slot area is the tile).  A subsequence of 32 bytes completes at most 128 symbols (a nibble completes two).  The 1024-thread
+// instantiation (one workgroup per CU) affords slots of 128 + 8 bytes; the 256-thread one must fit four workgroups per CU
+// (three measured 32 % SLOWER than the three-walk kernel, four 16 % faster: text 8 GiB 8.18 -> 6.88 ms), which leaves slots
+// of 80 + 8 bytes: blocks that average more than DCZ_DFA_REC_AVG symbols per subsequence keep the three walks, and a window
+// in which some subsequence still completes more than 80 (detected from the counts; the stores of such a lane run into its
+// neighbours' slots, never out of the area) is redone by the output walk.  Slot strides of 34 and 22 dwords keep the 8-byte
+// reads of 32 consecutive lanes on 32 different bank pairs.  The first 16 bytes of the area hold the bytes carried over
+// from the window before.
+#ifndef DCZ_DFA_SLOT_SMALL
+#define DCZ_DFA_SLOT_SMALL 88
+#endif
+#ifndef DCZ_DFA_REC_AVG
+#define DCZ_DFA_REC_AVG 60
+#endif
+constexpr int dfa_slot(int W) { return W > 512 ? 136 : DCZ_DFA_SLOT_SMALL; }
 template <int W, int OC>
 struct DfaLds {
-    static constexpr int CAP = OC + 512;  // tile capacity (the last lane of a flush may run 300 bytes past its end)
+    // tile capacity of the output walk (its last lane may run 300 bytes past the end of a flush); OC < 0: the slot area
+    // of the recording walk is the tile
+    static constexpr int CAP = (OC < 0) ? (16 + dfa_slot(W) * W - 512) : (OC + 512);
+    static constexpr int TILE_BYTES = CAP + 640;
     __attribute__((aligned(16))) uint32_t T[256 * 16];          // [state][nibble]
-    __attribute__((aligned(16))) uint32_t tile[CAP / 4 + 160];  // (+ slack)
+    union {
+        __attribute__((aligned(16))) uint32_t tile[TILE_BYTES / 4];
+        struct {  // scratch of the table build: dead once T is complete, and the tile is not touched before that
+            uint32_t node_p[256];  // prefix of internal node `id` (the l bits that lead to it)
+            uint32_t first[34], cnt[34], offs[34], nint[34], base[34];
+            uint8_t node_l[256];   // its depth
+            uint8_t symtab[256], len8[256];
+        };
+    };
     uint8_t exits[W];
-    uint8_t node_l[256];   // depth of internal node `id`
-    uint32_t node_p[256];  // its prefix (the l bits that lead to it)
-    uint32_t first[34], cnt[34], offs[34], nint[34], base[34];
     uint32_t wsum[W / 64];
     uint32_t flag[3];
-    uint8_t symtab[256], len8[256];
-    uint32_t maxlen, nstates, err_idx, cend_vote;
+    uint32_t maxlen, nstates, err_idx, cend_vote, zsym;
     int bad_table;
 };
 
@@ -158,14 +196,16 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 // (rounds of phase A only) and reports (entry state, symbols completed inside the region, exit state).
 // k4_split_scan proves the chain exit(r-1) == entry(r): equal states at the same byte are the same parse from there on.
 template <int W, int OC, int MODE, bool SPARSE>
-__global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
+__global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
     uint8_t* __restrict__ d_cls, const SplitDesc* __restrict__ sdp) {
     using LdsT = DfaLds<W, OC>;
     constexpr bool SPLIT = MODE == 1, COUNT = MODE == 2;
-    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : 8;
+    constexpr bool RECORD = OC < 0;  // the walk that counts also records the symbols (DfaLds: the slot area is the tile)
+    static_assert(!RECORD || (!SPARSE && !COUNT), "only the decoding passes of the dense automaton record");
+    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : OC < 0 ? DCZ_DFA_HOIST_DW_REC : 8;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -279,6 +319,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         L.node_p[id] = L.first[l] + L.cnt[l] + (id - L.base[l]);
     }
     __syncthreads();
+    if (tid == 0) L.zsym = L.symtab[0];  // the first canonical symbol (symtab shares its memory with the tile)
     for (uint32_t idx = (uint32_t)tid; idx < 256u * 16u; idx += W) {
         const uint32_t st = idx >> 4, nib = idx & 15u;
         uint32_t e = DFA_ERR << 6;  // unused rows and the error state: stay in the error state
@@ -371,9 +412,17 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
     const uint32_t sk2 = (skew + (uint32_t)(wbyte & 15ull)) & 15u;
     const uint32_t sq = sk2 >> 2, sr = sk2 & 3u;
     if (orig > 0 && wbyte < csize) prefetch(wbyte);
-    for (uint32_t i = (uint32_t)tid; i < (uint32_t)(sizeof(L.tile) / 16u); i += W)  // phase B ORs into the tile
-        reinterpret_cast<uint4*>(L.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();  // T complete
+    const uint32_t slot_addr = tile_addr + 16u + (uint32_t)dfa_slot(W) * (uint32_t)tid;  // RECORD: this lane's slot
+    __syncthreads();  // T complete; the scratch of the table build, which shares the tile's memory, is dead
+    // RECORD: does this block record?  (block-uniform; slots of 128 bytes take anything)
+    const bool rec_block = RECORD && (dfa_slot(W) - 8 >= 128 || (unsigned long long)orig_blk * 32ull <=
+                                                               (unsigned long long)csize * (unsigned long long)DCZ_DFA_REC_AVG);
+    auto zero_tile = [&](uint32_t from16) {  // the output walk ORs into a zeroed tile
+        for (uint32_t i = from16 + (uint32_t)tid; i < (uint32_t)(sizeof(L.tile) / 16u); i += W)
+            reinterpret_cast<uint4*>(L.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    };
+    if (!rec_block) zero_tile(0u);
     DFA_T(0);
 
     uint32_t rentry = 0, wexit = 0;  // COUNT: the region's entry state; every mode: state after the window's last subsequence
@@ -437,12 +486,43 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     [&]<int... Js>(std::integer_sequence<int, Js...>) {
                         (stepX(std::integral_constant<int, DCZ_DFA_X_FROM + Js>{}), ...);
                     }(std::make_integer_sequence<int, 64 - DCZ_DFA_X_FROM>{});
+                } else if (RECORD && rec_block) {
+                    // One walk counts AND records: the symbols of two nibbles (up to four bytes) are shifted into a
+                    // register at the lane's fill level and the dword under construction is stored into the lane's
+                    // private slot every time (a plain store: nobody else writes there); when it is full the spill-over
+                    // becomes the next dword.  The count is the fill level at the end.
+                    uint32_t ab = slot_addr, k8 = 0, alo = 0;
+                    auto stepR = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = 2 * decltype(jc)::value;
+                        constexpr int sh0 = 26 - 4 * (j & 7), sh1 = 26 - 4 * ((j + 1) & 7);
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
+                        const uint32_t nib0 = (R[j >> 3] >> sh0) & 0x3Cu;
+                        const uint32_t nib1 = sh1 >= 0 ? ((R[j >> 3] >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib0));
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & AMASK) | nib1));
+                        const uint32_t c0 = e0 & 0x18u;  // 8 * symbols of the first nibble (bytes past the count are zero)
+                        const uint32_t w = ((e >> 16) << c0) | (e0 >> 16);
+                        const unsigned long long v = (unsigned long long)w << k8;
+                        alo |= (uint32_t)v;
+                        *(lds_u32*)(uintptr_t)ab = alo;
+                        k8 += c0 + (e & 0x18u);
+                        const bool full = k8 >= 32u;
+                        alo = full ? (uint32_t)(v >> 32) : alo;
+                        ab += full ? 4u : 0u;
+                        k8 &= 31u;
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepR(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 32>{});
+                    *(lds_u32*)(uintptr_t)ab = alo;  // (the dword under construction; at most slot byte 128..131)
+                    n = (ab - slot_addr) + (k8 >> 3);
                 } else {
                     auto stepA = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
                         if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        DFA_FRESH_COPY(rj, R[j >> 3]);
+                        const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                         n += e & (SPARSE ? 7u : 3u);
                     };
@@ -487,7 +567,16 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
         // ---- offsets, errors ----
         const bool bad = !beyond && x == DFA_ERR;
         uint32_t tw = 0;
-        const uint32_t o = dfa_block_scan<W>(nsym, L, tw);
+        // (RECORD with small slots: a subsequence that ran over its slot rides along in bit 20 of the scanned value -- the
+        // counts of a window add up to < 2^16 -- so the window learns about it without another barrier)
+        constexpr uint32_t SLOT_SYMS = RECORD ? (uint32_t)dfa_slot(W) - 8u : 0u;
+        constexpr bool SLOT_CHECK = RECORD && SLOT_SYMS < 128u;
+        uint32_t o = dfa_block_scan<W>(nsym + ((SLOT_CHECK && !beyond && nsym > SLOT_SYMS) ? (1u << 20) : 0u), L, tw);
+        const bool slot_ran_over = SLOT_CHECK && (tw >> 20) != 0u;
+        if constexpr (SLOT_CHECK) {
+            o &= 0xFFFFFu;
+            tw &= 0xFFFFFu;
+        }
         const uint32_t remaining = orig - produced;
         if (bad) atomicMin(&L.err_idx, o + nsym);  // (the error state completes no symbol: nsym = symbols before it)
         // state after the last subsequence that starts inside the payload (the window's entry if none does)
@@ -537,7 +626,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             // filled it, later in that wave's program order, and one wave's stores reach memory in order: no fence, no
             // barrier, and the fill drains while the wave walks.
             {
-                const uint32_t z = L.symtab[0];
+                const uint32_t z = L.zsym;
                 const int lane = tid & 63;
                 uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
                 uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)(o + nsym), 63);
@@ -557,7 +646,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             }
 #else
             {
-                const uint32_t z = L.symtab[0];
+                const uint32_t z = L.zsym;
                 uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
                 if (head > lim) head = lim;
                 if ((uint32_t)tid < head) dst[tid] = (uint8_t)z;
@@ -631,6 +720,92 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             }
             (void)more;
         } else {
+        bool rec_win = rec_block;
+        if constexpr (SLOT_CHECK) {
+            if (rec_block && slot_ran_over) {  // workgroup-uniform: a slot ran over
+                rec_win = false;
+                zero_tile(1u);  // (the first 16 bytes hold the bytes carried over)
+                if ((uint32_t)tid >= ocarry && tid < 16) ob[tid] = 0;
+                __syncthreads();
+            }
+        }
+        if (RECORD && rec_win) {
+            // ---- phase B, recorded: close the slots up, in place, then flush ----
+            // Symbol i of the window belongs at byte ocarry + i of the area (the first ocarry bytes are carried over from
+            // the window before).  Lane l's destination ends below slot l + 1 and may lie anywhere in the slots of the
+            // lanes before it: every lane reads its whole slot into registers, barrier, then writes.  Whole dwords are
+            // written by one lane only; the <= 3 bytes in front of a lane's first whole dword and behind its last one
+            // share their dwords with the neighbours and go out as single bytes.
+            const uint32_t take = (o < lim) ? ((nsym < lim - o) ? nsym : lim - o) : 0u;
+            const uint32_t dpos = ocarry + o;
+            uint32_t hb = (4u - (dpos & 3u)) & 3u;
+            if (hb > take) hb = take;
+            const uint32_t nd = (take - hb) >> 2, tb = (take - hb) & 3u, shb = hb << 3;
+            uint32_t w[33];
+            [&]<int... Qs>(std::integer_sequence<int, Qs...>) __attribute__((always_inline)) {
+                ([&]() __attribute__((always_inline)) {
+                    constexpr int q = Qs;
+                    w[2 * q] = 0;
+                    w[2 * q + 1] = 0;
+                    if (__builtin_amdgcn_ballot_w64(take > 8u * (uint32_t)q) != 0ull) {  // wave-uniform
+                        const unsigned long long v2 =
+                            *(__attribute__((address_space(3))) const unsigned long long*)(uintptr_t)(slot_addr + 8u * (uint32_t)q);
+                        w[2 * q] = (uint32_t)v2;
+                        w[2 * q + 1] = (uint32_t)(v2 >> 32);
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, 16>{});
+            w[32] = 0;
+            uint32_t tailv;
+            {
+                const uint32_t t0 = *(lds_cu32*)(uintptr_t)(slot_addr + 4u * nd);
+                const uint32_t t1 = *(lds_cu32*)(uintptr_t)(slot_addr + 4u * nd + 4u);
+                tailv = __builtin_amdgcn_alignbit(t1, t0, shb);
+            }
+            __syncthreads();
+            {
+                typedef __attribute__((address_space(3))) uint8_t lds_u8;
+                const uint32_t dst = tile_addr + dpos, d4 = dst + hb;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if ((uint32_t)i < hb) *(lds_u8*)(uintptr_t)(dst + (uint32_t)i) = (uint8_t)(w[0] >> (8 * i));
+                [&]<int... Ks>(std::integer_sequence<int, Ks...>) __attribute__((always_inline)) {
+                    ([&]() __attribute__((always_inline)) {
+                        constexpr int k = Ks;
+                        if ((uint32_t)k < nd)
+                            *(lds_u32*)(uintptr_t)(d4 + 4u * (uint32_t)k) = __builtin_amdgcn_alignbit(w[k + 1], w[k], shb);
+                    }(), ...);
+                }(std::make_integer_sequence<int, 32>{});
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if ((uint32_t)i < tb) *(lds_u8*)(uintptr_t)(d4 + 4u * nd + (uint32_t)i) = (uint8_t)(tailv >> (8 * i));
+            }
+            DFA_T(5);
+            __syncthreads();
+            DFA_T(6);
+            const uint32_t total = ocarry + lim;
+            const uint32_t full = more ? (total & ~15u) : total;  // final flush of the block: store the ragged tail too
+            uint8_t* const dst = obase + gpos;
+            const uint32_t nunits = (full + 15u) >> 4;
+            for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
+                const uint32_t lo = u << 4;
+                const uint32_t* src = &L.tile[lo >> 2];
+                if (out_aligned && lo + 16u <= full && lo >= hskip) {
+                    *reinterpret_cast<uint4*>(dst + lo) = make_uint4(src[0], src[1], src[2], src[3]);
+                } else {
+                    for (uint32_t i = lo > hskip ? lo : hskip; i < lo + 16u && i < full; i++) dst[i] = ob[i];
+                }
+            }
+            const uint32_t tail = total - full;  // < 16
+            uint8_t tv = 0;
+            if ((uint32_t)tid < tail) tv = ob[full + tid];
+            __syncthreads();
+            if ((uint32_t)tid < tail) ob[tid] = tv;  // the ragged tail moves to the front of the area
+            gpos += full;
+            ocarry = tail;
+            if (full > 0u) hskip = 0;  // (the unit shared with the region before has been written)
+            DFA_T(7);
+        } else {
         // ---- phase B: the same walk from the final entry state, two byte stores per step ----
         for (uint32_t cbase = 0; cbase < lim;) {
             uint32_t cc = lim - cbase;
@@ -670,8 +845,9 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
                     constexpr int j = 2 * decltype(jc)::value;
                     constexpr int sh0 = 26 - 4 * (j & 7), sh1 = 26 - 4 * ((j + 1) & 7);
                     if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                    const uint32_t nib0 = (R[j >> 3] >> sh0) & 0x3Cu;
-                    const uint32_t nib1 = sh1 >= 0 ? ((R[j >> 3] >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                    DFA_FRESH_COPY(rj, R[j >> 3]);
+                    const uint32_t nib0 = (rj >> sh0) & 0x3Cu;
+                    const uint32_t nib1 = sh1 >= 0 ? ((rj >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                     const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib0));
                     e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & AMASK) | nib1));
                     const uint32_t c0 = e0 & tmask;  // 8 * symbols of the first nibble (bytes past the count are zero)
@@ -734,6 +910,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             if (cbase < lim) __syncthreads();  // (the next flush reads the bytes carried over)
         }
         }
+        }
         produced += lim;
         entry0 = next_entry;
         wbyte += (unsigned long long)W * 32ull;
@@ -745,7 +922,7 @@ __global__ __launch_bounds__(W, W <= 512 ? DCZ_DFA_MINWAVES : 1) void k4_dfa(
             // symbol, forever.  Zeros that leave the code tree are the reference's "decode error at position produced".
             __syncthreads();
             if (!SPARSE && (uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[tid];  // unflushed tail
-            const uint8_t z = L.symtab[0];
+            const uint8_t z = L.zsym;
             uint32_t fs = z;
             if (tid == 0) {
                 uint32_t st = wexit;
@@ -804,7 +981,7 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
     const unsigned long long* off = reinterpret_cast<const unsigned long long*>(d_comp_off);
     long long* ep = reinterpret_cast<long long*>(d_errpos);
     if (split_grid) {  // one workgroup per (block, region)
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, 1, false>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DFA_OC_DECODE, 1, false>), dim3(split_grid), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, ws.sdesc);
         return;
     }
@@ -813,14 +990,14 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
         return e ? (uint32_t)atoi(e) : 768u;
     }();
     if (K >= few_below) {  // 4 workgroups of 4 waves per CU
-        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_OC, 0, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
+        hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DFA_OC_DECODE, 0, false>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off,
                            d_comp_size, d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
         hipLaunchKernelGGL((k4_dfa<DCZ_DFA_W, DCZ_DFA_SPARSE_OC, 0, true>), dim3(K), dim3(DCZ_DFA_W), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #endif
     } else {  // few blocks: one 16-wave workgroup per block owns its CU (a window is 32 KiB of payload)
-        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_OC, 0, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<1024, DCZ_DFA_RECORD ? -1 : 4 * DCZ_DFA_OC, 0, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
         hipLaunchKernelGGL((k4_dfa<1024, 0, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,

@@ -58,7 +58,18 @@ def assert_parity(svc, orc, data, block_bytes):
         raise AssertionError("payload differs at byte %d of %d (hip %02x oracle %02x)" % (i, pay.size, pay[i], opay[i]))
     dec, st, _ = hip_decompress(svc, blk, data.size, block_bytes)
     assert (st == 0).all()
-    assert dec.size == data.size and (dec == data).all(), "decode differs from the input"
+    assert dec.size == data.size
+    if not (dec == data).all():
+        bad = np.nonzero(dec != data)[0]
+        b = int(bad[0]) // block_bytes
+        l = lens[b]
+        nb = min(block_bytes, data.size - b * block_bytes)
+        raise AssertionError(
+            "decode differs from the input: %d bytes in blocks %s of %d; block %d: %d bytes, payload %d at offset %d, %d symbols, "
+            "lengths %s, first bad byte %d (got %s want %s); launch shapes %s" % (
+                bad.size, np.unique(bad // block_bytes)[:8].tolist(), sizes.size, b, nb, sizes[b], offs[b], int((l > 0).sum()),
+                sorted(set(l[l > 0].tolist())), int(bad[0]) - b * block_bytes, dec[bad[0]:bad[0] + 8].tolist(),
+                data[bad[0]:bad[0] + 8].tolist(), svc.ctx.launch_shapes()))
     return blk
 
 
@@ -1262,6 +1273,32 @@ def _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym):
             assert ep[k] == wpos, "block %d: error position %d, oracle %d" % (k, ep[k], wpos)
         else:
             assert (out[k * stride:k * stride + origs[k]] == wdata).all(), "block %d decodes differently" % k
+
+
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks", "one_large_block"])
+def test_recording_walk_slots_that_run_over_and_blocks_that_do_not_record(pkg, svc, orc, shape):
+    """k4_dfa's recording walk gives every 32-byte subsequence a slot of 80 symbols (256-thread workgroups; 128 with 1024
+    threads).  Text with bursts of its shortest codeword completes up to 128 symbols per subsequence: the windows that hold
+    a burst are redone by the output walk, the others are not.  Blocks that average more than 60 symbols per subsequence
+    (< 4.27 bits per symbol, still the medium class) do not record at all.  All three launch shapes of the automaton."""
+    rng = np.random.default_rng(17)
+    bb, K = {"many_blocks": (16384, 900), "few_blocks": (1 << 20, 5), "one_large_block": (8 << 20, 1)}[shape]
+    n = bb * K - 123
+    text = orc.gen_text(23, 0, n).copy()
+    top = int(np.bincount(text, minlength=256).argmax())
+    for pos in rng.integers(0, n - 3000, size=max(8, n // 200000)):  # bursts inside blocks and across block boundaries
+        text[int(pos):int(pos) + int(rng.integers(200, 2500))] = top
+    blk = assert_parity(svc, orc, text, bb)
+    lens = blk.code_lengths.cpu().numpy()
+    assert lens[:, top].min() <= 3, "the burst symbol must be short enough to overrun a slot of 80"
+    bits = 8.0 * blk.comp_size.cpu().numpy().sum() / n
+    assert bits >= 4.27, "these blocks are meant to record (%.2f bits per symbol)" % bits
+    # ~3.9 bits per symbol: medium class, more than 60 symbols per subsequence on average
+    pr = np.r_[np.full(8, 3.0), np.full(8, 1.0)]
+    dense = rng.choice(16, size=n, p=pr / pr.sum()).astype(np.uint8) + 40
+    blk = assert_parity(svc, orc, dense, bb)
+    bits = 8.0 * blk.comp_size.cpu().numpy().sum() / n
+    assert 3.6 < bits < 4.27, "these blocks are meant to stay with the three walks (%.2f bits per symbol)" % bits
 
 
 @pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
