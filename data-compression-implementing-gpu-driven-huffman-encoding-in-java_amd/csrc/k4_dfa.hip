@@ -55,7 +55,7 @@ namespace dcz {
 #define DFA_FRESH_COPY(dst, r)                                    \
     uint32_t dst = (r);                                           \
     do {                                                          \
-        if constexpr (RECORD) asm volatile("" : "+v"(dst));       \
+        if constexpr (RECORD || SPARSE) asm volatile("" : "+v"(dst)); \
     } while (0)
 #ifndef DCZ_DFA_HOIST_DW_SPLIT
 #define DCZ_DFA_HOIST_DW_SPLIT 3
@@ -70,13 +70,8 @@ namespace dcz {
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
 #ifndef DCZ_DFA_SPARSE_OC
-#define DCZ_DFA_SPARSE_OC 0  // SPARSE has no tile; a non-zero value only reserves LDS, i.e. limits the workgroups per CU
-#endif
-#ifndef DCZ_DFA_SPARSE_WAVEFILL
-#define DCZ_DFA_SPARSE_WAVEFILL 0  // SPARSE, 1: every wave fills its own output range, no fence (bit-exact in every test, but it
-                                   // leans on one wave's stores reaching memory in order across lanes, and measures the
-                                   // same: 3.12 vs 3.02 ms -- the kernel is bound by its write traffic, not by the wait)
-#endif
+#define DCZ_DFA_SPARSE_OC 13312  // SPARSE: bytes of output composed per chunk (a window is ~60 KiB of output): what four workgroups
+#endif                           // per CU leave after the table (16 KiB) and the lists (8.6 KiB)
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
@@ -116,12 +111,16 @@ constexpr uint32_t DFA_ERR = 255;  // sticky state: the stream left the code tre
 #define DCZ_DFA_REC_AVG 60
 #endif
 constexpr int dfa_slot(int W) { return W > 512 ? 136 : DCZ_DFA_SLOT_SMALL; }
-template <int W, int OC>
+// SPARSE: the walk that counts records the symbols other than z as (position inside the subsequence, byte) pairs of 16 bits in
+// a per-lane list of DFA_PCAP entries (+ 1: the entry under construction); the window's output is then composed in LDS,
+// chunk by chunk, and written ONCE (PL > 0: the tile is a chunk of OC bytes).
+constexpr int DFA_PCAP = 16;
+template <int W, int OC, int PL = 0>
 struct DfaLds {
     // tile capacity of the output walk (its last lane may run 300 bytes past the end of a flush); OC < 0: the slot area
     // of the recording walk is the tile
     static constexpr int CAP = (OC < 0) ? (16 + dfa_slot(W) * W - 512) : (OC + 512);
-    static constexpr int TILE_BYTES = CAP + 640;
+    static constexpr int TILE_BYTES = PL ? (OC + 64) : (CAP + 640);
     __attribute__((aligned(16))) uint32_t T[256 * 16];          // [state][nibble]
     union {
         __attribute__((aligned(16))) uint32_t tile[TILE_BYTES / 4];
@@ -132,6 +131,9 @@ struct DfaLds {
             uint8_t symtab[256], len8[256];
         };
     };
+    // (a lane that meets more than PL symbols other than z writes on into its neighbours' lists -- the window is then
+    // redone -- and at most 128 entries far: the slack keeps the last lanes inside)
+    uint16_t plist[PL ? W * (PL + 1) + 128 : 2];
     uint8_t exits[W];
     uint32_t wsum[W / 64];
     uint32_t flag[3];
@@ -201,11 +203,11 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
     uint8_t* __restrict__ d_cls, const SplitDesc* __restrict__ sdp) {
-    using LdsT = DfaLds<W, OC>;
+    using LdsT = DfaLds<W, OC, SPARSE ? DFA_PCAP : 0>;
     constexpr bool SPLIT = MODE == 1, COUNT = MODE == 2;
     constexpr bool RECORD = OC < 0;  // the walk that counts also records the symbols (DfaLds: the slot area is the tile)
     static_assert(!RECORD || (!SPARSE && !COUNT), "only the decoding passes of the dense automaton record");
-    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : OC < 0 ? DCZ_DFA_HOIST_DW_REC : 8;
+    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : (OC < 0 || SPARSE) ? DCZ_DFA_HOIST_DW_REC : 8;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -422,7 +424,11 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             reinterpret_cast<uint4*>(L.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     };
-    if (!rec_block) zero_tile(0u);
+    if (!rec_block) zero_tile(0u);  // (SPARSE: the chunk tile holds byte ^ z over a zero background)
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t pl_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t*)(&L.plist[0])) +
+                             2u * (uint32_t)(DFA_PCAP + 1) * (uint32_t)tid;  // SPARSE: this lane's patch list
     DFA_T(0);
 
     uint32_t rentry = 0, wexit = 0;  // COUNT: the region's entry state; every mode: state after the window's last subsequence
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         // walks as long as any of its lanes does, so lanes whose guess was right cost nothing extra and get their count
         // here too); later rounds (rare) re-walk the lanes whose entry still changed.
         uint32_t g = (tid == 0) ? entry0 : 0u;  // entry state
-        uint32_t x = 0, nsym = 0;
+        uint32_t x = 0, nsym = 0, pc = 0;  // pc (SPARSE): symbols other than z this lane has recorded
         bool need = !beyond;
         uint32_t round = (DCZ_DFA_ABL & 4) ? 1u : 0u;
         while (true) {
@@ -486,6 +492,33 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     [&]<int... Js>(std::integer_sequence<int, Js...>) {
                         (stepX(std::integral_constant<int, DCZ_DFA_X_FROM + Js>{}), ...);
                     }(std::make_integer_sequence<int, 64 - DCZ_DFA_X_FROM>{});
+                } else if constexpr (SPARSE) {
+                    // One walk counts and records: (index inside the subsequence, byte) of every symbol other than z goes
+                    // into the lane's list.  The entry is stored every step and the list pointer moves on only when the
+                    // nibble had such a symbol; two in one nibble (1 step in 10^4 on 1 % noise) take the branch.
+                    uint32_t pa = pl_addr;
+                    auto stepP = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int sh = 26 - 4 * (j & 7);
+                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
+                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
+                        const uint32_t oth = e & 0x18u;  // 8 * symbols other than z
+                        const uint32_t tp = n + ((e >> 14) & 3u);
+                        *(lds_u16*)(uintptr_t)pa = (uint16_t)(tp | ((e >> 8) & 0xFF00u));
+                        if (__builtin_amdgcn_ballot_w64(oth == 0x10u) != 0ull) {
+                            if (oth == 0x10u) {  // sym0 is the nibble's first symbol, sym1 the one at index pos
+                                *(lds_u16*)(uintptr_t)pa = (uint16_t)(n | ((e >> 8) & 0xFF00u));
+                                *(lds_u16*)(uintptr_t)(pa + 2u) = (uint16_t)(tp | ((e >> 16) & 0xFF00u));
+                            }
+                        }
+                        pa += oth >> 2;
+                        n += e & 7u;
+                    };
+                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
+                        (stepP(std::integral_constant<int, Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64>{});
+                    if (need) pc = (pa - pl_addr) >> 1;
                 } else if (RECORD && rec_block) {
                     // One walk counts AND records: the symbols of two nibbles (up to four bytes) are shifted into a
                     // register at the lane's fill level and the dword under construction is stored into the lane's
@@ -570,8 +603,9 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         // (RECORD with small slots: a subsequence that ran over its slot rides along in bit 20 of the scanned value -- the
         // counts of a window add up to < 2^16 -- so the window learns about it without another barrier)
         constexpr uint32_t SLOT_SYMS = RECORD ? (uint32_t)dfa_slot(W) - 8u : 0u;
-        constexpr bool SLOT_CHECK = RECORD && SLOT_SYMS < 128u;
-        uint32_t o = dfa_block_scan<W>(nsym + ((SLOT_CHECK && !beyond && nsym > SLOT_SYMS) ? (1u << 20) : 0u), L, tw);
+        constexpr bool SLOT_CHECK = (RECORD && SLOT_SYMS < 128u) || SPARSE;
+        const bool ran_over = !beyond && (SPARSE ? pc > (uint32_t)DFA_PCAP : nsym > SLOT_SYMS);
+        uint32_t o = dfa_block_scan<W>(nsym + ((SLOT_CHECK && ran_over) ? (1u << 20) : 0u), L, tw);
         const bool slot_ran_over = SLOT_CHECK && (tw >> 20) != 0u;
         if constexpr (SLOT_CHECK) {
             o &= 0xFFFFFu;
@@ -618,88 +652,98 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         DFA_T(4);
 
         if constexpr (SPARSE) {
-            // ---- phase B, sparse: fill the window's output with z, then the same walk stores the other symbols ----
-            uint8_t* const dst = oblk + produced;  // lim bytes
-#if DCZ_DFA_SPARSE_WAVEFILL
-            // Every WAVE fills exactly the bytes its own lanes own -- [o of its lane 0, o + nsym of its lane 63), clipped to
-            // lim; the ranges of consecutive waves abut -- and then walks.  A byte is only ever stored by the wave that
-            // filled it, later in that wave's program order, and one wave's stores reach memory in order: no fence, no
-            // barrier, and the fill drains while the wave walks.
-            {
-                const uint32_t z = L.zsym;
-                const int lane = tid & 63;
-                uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
-                uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)(o + nsym), 63);
-                if (ws > lim) ws = lim;
-                if (we > lim) we = lim;
-                uint8_t* const fd = dst + ws;
-                const uint32_t len = we - ws;
-                uint32_t head = (16u - (uint32_t)((uintptr_t)fd & 15u)) & 15u;
-                if (head > len) head = len;
-                if ((uint32_t)lane < head) fd[lane] = (uint8_t)z;
-                const uint32_t body = (len - head) >> 4;
-                const uint32_t z4 = z * 0x01010101u;
-                uint4* const d4 = reinterpret_cast<uint4*>(fd + head);
-                for (uint32_t u = (uint32_t)lane; u < body; u += 64u) d4[u] = make_uint4(z4, z4, z4, z4);
-                const uint32_t t0 = head + (body << 4);
-                if ((uint32_t)lane < len - t0) fd[t0 + lane] = (uint8_t)z;
-            }
-#else
-            {
-                const uint32_t z = L.zsym;
-                uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
-                if (head > lim) head = lim;
-                if ((uint32_t)tid < head) dst[tid] = (uint8_t)z;
-                const uint32_t body = (lim - head) >> 4;
-                const uint32_t z4 = z * 0x01010101u;
-                uint4* const d4 = reinterpret_cast<uint4*>(dst + head);
-                for (uint32_t u = (uint32_t)tid; u < body; u += W) d4[u] = make_uint4(z4, z4, z4, z4);
-                const uint32_t t0 = head + (body << 4);
-                if ((uint32_t)tid < lim - t0) dst[t0 + tid] = (uint8_t)z;
-            }
-            // Workgroup-scope release + barrier: the fill of every wave is ordered before the single-byte stores any other
-            // wave of this workgroup issues afterwards to the same lines (one CU, one L1, same-address order; a device-
-            // scope fence here costs 8x the whole kernel, see k4_decode.hip).
-            __threadfence_block();
-            __syncthreads();
-#endif
-            const bool mine = nsym > 0u && o < lim;
-            // Only the subsequence that straddles lim (the end of the block) needs its stores checked: waves without it
-            // take a walk whose store block is as small as it gets -- the store executes whenever ANY lane of the wave has
-            // a symbol other than z in the step (9 steps of 10 on 1 % noise), so its instructions count for all lanes.
-            const bool inside = o + nsym <= lim;
-            if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
-                uint32_t e = g << 6;
-                DFA_FRESH(R);
-                uint32_t t = o;
-                const uint32_t cmask = mine ? 7u : 0u, zmask = mine ? 0x18u : 0u;  // switched-off lanes store nothing
-                if (__builtin_amdgcn_ballot_w64(mine && !inside) == 0ull) {  // wave-uniform
-                    auto stepF = [&](auto jc) __attribute__((always_inline)) {
-                        constexpr int j = decltype(jc)::value;
-                        constexpr int sh = 26 - 4 * (j & 7);
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
-                        e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
-                        const uint32_t nz = e & zmask;
-                        if (nz != 0u) {
-                            const uint32_t tp = t + ((e >> 14) & 3u);
-                            const bool two = nz == 0x10u;  // (1 step in 10^4: sym0 at t, sym1 at tp)
-                            dst[two ? t : tp] = (uint8_t)(e >> 16);
-                            if (__builtin_amdgcn_ballot_w64(two) != 0ull) {
-                                if (two) dst[tp] = (uint8_t)(e >> 24);
+            const uint32_t z = L.zsym, z4 = z * 0x01010101u;
+            if (!slot_ran_over) {
+                // ---- phase B, sparse: the window's output is composed in LDS, chunk by chunk, and written once ----
+                // Every byte of the window is z unless a list says otherwise.  The tile holds byte ^ z over a zero
+                // background: the lanes whose symbols fall into the chunk drop their entries in, the flush turns units of 16
+                // bytes into output (tile ^ zzzz, aligned 16-byte stores) and zeroes them again.  As in the dense kernels the
+                // first ocarry bytes of the tile are the ones carried over (the output position is not a multiple of 16).
+                const uint32_t pcn = (!beyond && nsym > 0u) ? pc : 0u;
+                for (uint32_t cbase = 0; cbase < lim;) {
+                    const uint32_t room = (uint32_t)OC - ocarry;
+                    const uint32_t cc = (lim - cbase < room) ? lim - cbase : room;
+                    const uint32_t cend = cbase + cc;
+                    {
+                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+                        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(o + nsym), 63);
+                        if (whi > cbase && wlo < cend) {  // wave-uniform: this wave's symbols meet the chunk
+                            for (uint32_t i = 0; __builtin_amdgcn_ballot_w64(i < pcn) != 0ull; i++) {
+                                if (i < pcn) {
+                                    const uint32_t e16 = *(lds_u16*)(uintptr_t)(pl_addr + 2u * i);
+                                    const uint32_t pos = o + (e16 & 0xFFu);
+                                    if (pos >= cbase && pos < cend)
+                                        *(lds_u8*)(uintptr_t)(tile_addr + ocarry + (pos - cbase)) = (uint8_t)((e16 >> 8) ^ z);
+                                }
                             }
                         }
-                        t += e & cmask;
-                    };
-                    [&]<int... Js>(std::integer_sequence<int, Js...>) {
-                        (stepF(std::integral_constant<int, Js>{}), ...);
-                    }(std::make_integer_sequence<int, 64>{});
-                } else {
+                    }
+                    __syncthreads();
+                    const uint32_t total = ocarry + cc;
+                    const bool last = !more && cend == lim;  // final flush of the block: store the ragged tail too
+                    const uint32_t full = last ? total : (total & ~15u);
+                    uint8_t* const dst = obase + gpos;
+                    const uint32_t nunits = (full + 15u) >> 4;
+                    for (uint32_t u = (uint32_t)tid; u < nunits; u += W) {
+                        const uint32_t lo = u << 4;
+                        uint4* const src = reinterpret_cast<uint4*>(&L.tile[lo >> 2]);
+                        const uint4 v = *src;
+                        if (out_aligned && lo + 16u <= full && lo >= hskip) {
+                            *reinterpret_cast<uint4*>(dst + lo) = make_uint4(v.x ^ z4, v.y ^ z4, v.z ^ z4, v.w ^ z4);
+                        } else {
+                            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                            for (uint32_t i = lo > hskip ? lo : hskip; i < lo + 16u && i < full; i++)
+                                dst[i] = (uint8_t)((wv[(i - lo) >> 2] >> (8u * (i & 3u))) ^ z);
+                        }
+                        *src = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    const uint32_t tail = total - full;  // < 16: bytes that wait for the next chunk (still byte ^ z)
+                    uint8_t tv = 0;
+                    if ((uint32_t)tid < tail) tv = ob[full + tid];
+                    __syncthreads();
+                    if (full > 0u) {
+                        if (tid < 4) L.tile[(full >> 2) + (uint32_t)tid] = 0u;
+                        if ((uint32_t)tid < tail) ob[tid] = tv;
+                    }
+                    gpos += full;
+                    ocarry = tail;
+                    if (full > 0u) hskip = 0;
+                    cbase = cend;
+                    __syncthreads();
+                }
+            } else {
+                // ---- a list ran over (more than DFA_PCAP symbols other than z in one subsequence): this window goes to
+                // global memory the way every window used to: fill with z, then a third walk stores the other symbols ----
+                if ((uint32_t)tid >= hskip && (uint32_t)tid < ocarry) obase[gpos + tid] = (uint8_t)(ob[tid] ^ z);  // bytes carried over
+                __syncthreads();
+                if (tid < 4) L.tile[tid] = 0u;
+                uint8_t* const dst = oblk + produced;  // lim bytes
+                {
+                    uint32_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+                    if (head > lim) head = lim;
+                    if ((uint32_t)tid < head) dst[tid] = (uint8_t)z;
+                    const uint32_t body = (lim - head) >> 4;
+                    uint4* const d4 = reinterpret_cast<uint4*>(dst + head);
+                    for (uint32_t u = (uint32_t)tid; u < body; u += W) d4[u] = make_uint4(z4, z4, z4, z4);
+                    const uint32_t t0 = head + (body << 4);
+                    if ((uint32_t)tid < lim - t0) dst[t0 + tid] = (uint8_t)z;
+                }
+                // Workgroup-scope release + barrier: the fill of every wave is ordered before the single-byte stores any other
+                // wave of this workgroup issues afterwards to the same lines (one CU, one L1, same-address order; a device-
+                // scope fence here costs 8x the whole kernel, see k4_decode.hip).
+                __threadfence_block();
+                __syncthreads();
+                const bool mine = nsym > 0u && o < lim;
+                if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+                    uint32_t e = g << 6;
+                    uint32_t t = o;
+                    const uint32_t cmask = mine ? 7u : 0u, zmask = mine ? 0x18u : 0u;  // switched-off lanes store nothing
                     auto stepS = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
                         if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        DFA_FRESH_COPY(rj, R[j >> 3]);
+                        const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                         const uint32_t nz = e & zmask;
                         if (nz != 0u) {
@@ -717,6 +761,12 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                         (stepS(std::integral_constant<int, Js>{}), ...);
                     }(std::make_integer_sequence<int, 64>{});
                 }
+                // the next window starts in the middle of a 16-byte unit whose first bytes are in memory already
+                const uint32_t np = produced + lim;
+                gpos = np & ~15u;
+                ocarry = np & 15u;
+                hskip = ocarry;
+                __syncthreads();
             }
             (void)more;
         } else {
@@ -921,7 +971,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             // subsequence that starts inside the payload; everything after it is the all-zero codeword = first canonical
             // symbol, forever.  Zeros that leave the code tree are the reference's "decode error at position produced".
             __syncthreads();
-            if (!SPARSE && (uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = ob[tid];  // unflushed tail
+            if ((uint32_t)tid < ocarry && (uint32_t)tid >= hskip) obase[gpos + tid] = (uint8_t)(ob[tid] ^ (SPARSE ? L.zsym : 0u));  // unflushed tail
             const uint8_t z = L.zsym;
             uint32_t fs = z;
             if (tid == 0) {
@@ -1000,7 +1050,7 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
         hipLaunchKernelGGL((k4_dfa<1024, DCZ_DFA_RECORD ? -1 : 4 * DCZ_DFA_OC, 0, false>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #if DCZ_K4_SPARSE_DFA
-        hipLaunchKernelGGL((k4_dfa<1024, 0, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
+        hipLaunchKernelGGL((k4_dfa<1024, 4 * DCZ_DFA_SPARSE_OC, 0, true>), dim3(K), dim3(1024), 0, s, d_comp, off, d_comp_size,
                            d_orig_size, d_len, out_stride, d_out, d_status, ep, ws.cls, (const SplitDesc*)nullptr);
 #endif
     }

@@ -1366,6 +1366,26 @@ def test_sparse_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape,
     _decode_table_case(pkg, svc, orc, rng, lens, syms, probs, K, nsym)
 
 
+@pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
+def test_sparse_windows_composed_in_lds_and_windows_whose_lists_run_over(pkg, svc, orc, shape):
+    """k4_dfa's SPARSE instantiation records the symbols other than the 1-bit one in per-lane lists of 16 entries and
+    composes the window's output in LDS, written once; a window in which a list runs over is filled and patched in global
+    memory instead.  Zero pages with 1 % noise and bursts of 30 % noise: both kinds of window, in either order, with the
+    16-byte carry between them, in both launch shapes."""
+    rng = np.random.default_rng(29)
+    bb, K = (32768, 800) if shape == "many_blocks" else (2 << 20, 6)
+    n = bb * K - 77
+    data = orc.gen_lowentropy(0xD0C5, 0, n).copy()
+    for pos in rng.integers(0, n - 5000, size=max(10, n // 300000)):
+        ln = int(rng.integers(300, 4000))
+        burst = rng.integers(1, 256, size=ln).astype(np.uint8)
+        burst[rng.random(ln) > 0.3] = 0
+        data[int(pos):int(pos) + ln] = burst
+    blk = assert_parity(svc, orc, data, bb)
+    bits = 8.0 * blk.comp_size.cpu().numpy().astype(np.float64) / bb
+    assert (bits < 1.3).mean() > 0.8, "most blocks are meant to stay in the sparse class (%.0f %% do)" % (100 * (bits < 1.3).mean())
+
+
 @pytest.mark.parametrize("seed", range(160))
 def test_fuzz_decode_random_tables(pkg, svc, orc, seed):
     """Random length tables (Huffman codes of random histograms, complete or made incomplete by lengthening codewords) and

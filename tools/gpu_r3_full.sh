@@ -1,0 +1,12 @@
+#!/bin/bash
+# full GPU suite + the driver's command (default bench run with secondary workloads)
+R=$GRAFT_REPO_ROOT; cd $R
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3_tests.log 2>&1; rc=$?; echo "full tests rc=$rc"; tail -3 gpurun_out/r3_tests.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3_bench_default.json'))
+print("headline %.1f GB/s %.3f ms roofline %s %.3f" % (d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac']), d['launch_shapes'])
+for n,s in d.get('secondary',{}).items():
+    print("%-12s %8.1f GB/s %8.3f ms  roofline %s %.3f  k4 %.3f" % (n, s['value'], s['ms_per_step'], s['roofline']['kernel'], s['roofline']['frac'], s['kernels']['k4_decode']['avg_ms']))
+PY
