@@ -5,7 +5,7 @@
 set -o pipefail
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=$1; shift
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/st_$TAG -- python3 $R/bench.py --no-secondary "$@" --steps 3 --warmup 1 --cpu-sample-mib 0 > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_stats.err || echo "stats failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/st_$TAG -- python3 $R/bench.py --no-secondary "$@" --steps 20 --warmup 5 --cpu-sample-mib 0 > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_stats.err || echo "stats failed"
 cp $(ls $R/gpurun_out/st_$TAG/*/*_kernel_stats.csv | head -1) $R/gpurun_out/prof_${TAG}_kernel_stats.csv || echo "no stats csv"
 for P in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/trf_${TAG}_$P -- python3 $R/bench.py --no-secondary "$@" --steps 3 --warmup 1 --cpu-sample-mib 0 --no-verify > $R/gpurun_out/trf_${TAG}_$P.json 2> $R/gpurun_out/trf_${TAG}_$P.err || echo "pass $P failed"
