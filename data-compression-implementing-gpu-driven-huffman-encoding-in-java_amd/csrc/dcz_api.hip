@@ -16,7 +16,8 @@ struct dcz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;       // second stream: code build of one half overlaps K1/K3 of the other half
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux2 = nullptr;      // third stream: per-chunk SHA-256 of the host-batch twins beside the codec and the copies
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [5], [6]: hand-overs with aux2
     uint64_t* carry = nullptr;       // device u64: payload bytes of the first half
     bool pipeline = true;
     std::string err;
@@ -288,6 +289,7 @@ int dcz_ctx_create(int device, dcz_ctx** out) {
     DeviceGuard g(device);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->st_meta), 8192) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->carry), 64) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -320,6 +322,7 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     for (auto& ev : c->pending) {
         (void)hipEventDestroy(ev.a);
         (void)hipEventDestroy(ev.b);
@@ -341,6 +344,7 @@ void dcz_ctx_destroy(dcz_ctx* c) {
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -708,23 +712,38 @@ int dcz_compress_host(dcz_ctx* c, const uint8_t* in, size_t n, size_t block_byte
     if ((r = reserve_batch(c, K)) != DCZ_OK) return r;
     const BatchCols b = batch_at(c->st_batch, c->st_batch_K);
     HIPCHK(c, hipMemcpyAsync(c->st_in, in, n, hipMemcpyHostToDevice, s));
-    if (sha256) launch_sha256(c->st_in, n, block_bytes, g.K, b.sha, s);  // ChecksumUtil.computeSha256 per chunk (K5)
+    if (sha256) {
+        // ChecksumUtil.computeSha256 per chunk (K5): one lane per chunk, slow by construction (28 ms per GiB at 4 MiB chunks),
+        // so it runs on a stream of its own beside K1-K3 and beside the copy of the payload to the host
+        HIPCHK(c, hipEventRecord(c->ev[5], s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux2, c->ev[5], 0));
+        launch_sha256(c->st_in, n, block_bytes, g.K, b.sha, c->aux2);
+        HIPCHK(c, hipEventRecord(c->ev[6], c->aux2));
+    }
     r = dcz_compress_blocks(c, c->st_in, n, block_bytes, c->st_out, n, b.comp_size, b.comp_off, b.len, b.status, b.total, s);
-    if (r != DCZ_OK) return r;
+    if (r != DCZ_OK) {
+        if (sha256) (void)hipStreamSynchronize(c->aux2);
+        return r;
+    }
     uint64_t tot = 0;
     HIPCHK(c, hipMemcpyAsync(comp_size, b.comp_size, 4 * K, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(comp_off, b.comp_off, 8 * K, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(len, b.len, 256 * K, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(status, b.status, 4 * K, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&tot, b.total, 8, hipMemcpyDeviceToHost, s));
-    if (sha256) HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (total) *total = tot;
-    for (size_t k = 0; k < K; k++)
-        if (status[k] != DCZ_OK) return status[k];
-    if (tot > out_cap) return DCZ_E_CAPACITY;
-    if (tot) HIPCHK(c, hipMemcpyAsync(out, c->st_out, tot, hipMemcpyDeviceToHost, s));
+    int bad = DCZ_OK;
+    for (size_t k = 0; k < K && bad == DCZ_OK; k++)
+        if (status[k] != DCZ_OK) bad = status[k];
+    if (bad == DCZ_OK && tot > out_cap) bad = DCZ_E_CAPACITY;
+    if (bad == DCZ_OK && tot) HIPCHK(c, hipMemcpyAsync(out, c->st_out, tot, hipMemcpyDeviceToHost, s));  // beside the digests
+    if (sha256) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));  // (the staging buffers are reused by the next call: always wait)
+        if (bad == DCZ_OK) HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(c, hipStreamSynchronize(s));
+    if (bad != DCZ_OK) return bad;
     return launch_check(c);
 }
 
@@ -758,11 +777,19 @@ int dcz_decompress_host(dcz_ctx* c, const uint8_t* comp, size_t comp_bytes, cons
     // contiguous: every chunk but the last fills its stride
     bool contiguous = sha256 != nullptr;
     for (size_t k = 0; contiguous && k + 1 < K; k++) contiguous = orig_size[k] == out_stride;
-    if (contiguous) launch_sha256(c->st_out, last, out_stride, (uint32_t)K, b.sha, s);
+    if (contiguous) {  // the digests of the decoded chunks are computed while the chunks travel to the host
+        HIPCHK(c, hipEventRecord(c->ev[5], s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux2, c->ev[5], 0));
+        launch_sha256(c->st_out, last, out_stride, (uint32_t)K, b.sha, c->aux2);
+        HIPCHK(c, hipEventRecord(c->ev[6], c->aux2));
+    }
     HIPCHK(c, hipMemcpyAsync(status, b.status, 4 * K, hipMemcpyDeviceToHost, s));
     if (errpos) HIPCHK(c, hipMemcpyAsync(errpos, b.errpos, 8 * K, hipMemcpyDeviceToHost, s));
-    if (contiguous) HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
     if (last) HIPCHK(c, hipMemcpyAsync(out, c->st_out, last, hipMemcpyDeviceToHost, s));
+    if (contiguous) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
+        HIPCHK(c, hipMemcpyAsync(sha256, b.sha, 32 * K, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(c, hipStreamSynchronize(s));
     r = launch_check(c);
     if (r != DCZ_OK) return r;

@@ -279,6 +279,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, LdsT& L, ui
     return base + inc - v;
 }
 
+#if DCZ_K4_PROF
+// debug build only: cycles per phase, summed over wave 0 of every workgroup (tools/k4prof.py)
+__device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds (wave 0 of each workgroup)
+#define PROF_T(i)                                         \
+    do {                                                  \
+        const unsigned long long t_ = clock64();          \
+        pacc[i] += t_ - plast;                            \
+        plast = t_;                                       \
+    } while (0)
+#else
+#define PROF_T(i) do { } while (0)
+#endif
+
 // ---- exact entries for windows that do not self-synchronise ------------------------------------------------------
 // Streams of (nearly) equal-length codewords whose length does not divide the subsequence keep a wrong phase for ever, so
 // the fixed point of phase A advances one subsequence per round.  After DCZ_K4_EXACT_AFTER rounds a window switches to
@@ -345,14 +358,36 @@ __device__ __attribute__((noinline)) void k4_exact_entries(uint32_t ftab_a, uint
         x0 = run(g0, 0u, tid == 0u && !beyond, landed) & 31u;
     }
     __syncthreads();
-    if (tid == 0u) {
-        __attribute__((address_space(3))) uint16_t* const ex = (__attribute__((address_space(3))) uint16_t*)(uintptr_t)exits_a;
-        uint32_t e = x0;
-        ex[0] = (uint16_t)e;
-        for (uint32_t q = 1; q < (uint32_t)W; q++) {
-            e = (uint32_t)((lds_u8*)(uintptr_t)(ftab_a + 32u * q))[e & 31u] & 31u;
-            ex[q] = (uint16_t)e;
+#if DCZ_K4_PROF
+    const unsigned long long pc0 = clock64();
+#endif
+    // entry(q + 1) = F_q[entry(q)] over the window's W subsequences.  One lane walking all of them was 29 % of K4's time on
+    // such streams (336 cycles per dependent step, tools/k4prof_dist.py), so every wave first composes its own 64
+    // subsequences for EVERY possible entry (lane = entry offset at the wave's first subsequence; the composed row
+    // replaces F_q in place: a wave's LDS operations execute in order, the reads of a step precede its writes), then
+    // the W/64 wave entries are chained, then every subsequence looks its exit up.
+    {
+        lds_u8* const ft = (lds_u8*)(uintptr_t)ftab_a;
+        const uint32_t w0 = tid & ~63u, lane = tid & 63u;
+        if (lane < 32u) {
+            uint32_t cur = lane;
+            for (uint32_t k = (w0 == 0u) ? 1u : 0u; k < 64u; k++) {  // (subsequence 0's exit is x0, decoded above)
+                const uint32_t q = w0 + k;
+                cur = (uint32_t)ft[32u * q + cur] & 31u;
+                ft[32u * q + lane] = (uint8_t)cur;
+            }
         }
+        __syncthreads();
+        // entry of every wave's first subsequence (of subsequence 1 for wave 0): x0, then the composed last rows
+        __attribute__((address_space(3))) uint16_t* const ex = (__attribute__((address_space(3))) uint16_t*)(uintptr_t)exits_a;
+        if (tid == 0u) ex[0] = (uint16_t)x0;  // (only thread 0's x0 is real)
+        __syncthreads();
+        uint32_t ent = (uint32_t)ex[0];
+        for (uint32_t w = 64u; w <= w0; w += 64u) ent = (uint32_t)ft[32u * (w - 1u) + ent] & 31u;
+        if (tid != 0u) ex[tid] = (uint16_t)((uint32_t)ft[32u * tid + ent] & 31u);
+#if DCZ_K4_PROF
+        if (tid == 0u) atomicAdd(&k4_prof[11], clock64() - pc0);  // the chain over the window's subsequences
+#endif
     }
     __syncthreads();
     {
@@ -363,18 +398,6 @@ __device__ __attribute__((noinline)) void k4_exact_entries(uint32_t ftab_a, uint
     __syncthreads();
 }
 
-#if DCZ_K4_PROF
-// debug build only: cycles per phase, summed over wave 0 of every workgroup (tools/k4prof.py)
-__device__ unsigned long long k4_prof[12];  // [8] windows, [9] self-sync rounds (wave 0 of each workgroup)
-#define PROF_T(i)                                         \
-    do {                                                  \
-        const unsigned long long t_ = clock64();          \
-        pacc[i] += t_ - plast;                            \
-        plast = t_;                                       \
-    } while (0)
-#else
-#define PROF_T(i) do { } while (0)
-#endif
 
 // CMASK: the block classes this instantiation decodes (bit 2: >= 6.5 bits per symbol on average, bit 1: at most 72
 // symbols per 32-byte subsequence, bit 0: shorter codes); every launch covers all blocks and each workgroup leaves at
@@ -708,7 +731,14 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
                 slow_block = true;
             }
         };
+#if DCZ_K4_PROF
+        const unsigned long long px0 = clock64();
+#endif
         if (slow_block) take_exact_entries();  // workgroup-uniform: an earlier window of this block did not converge
+#if DCZ_K4_PROF
+        pacc[10] += clock64() - px0;  // (inside "A decode" of tools/k4prof.py: the exact-entry procedure)
+        plast = clock64();
+#endif
         while (true) {
             // Integer-only inner loop.  Per stream: np = descending bit position, nl = position of its limit
             // (stream active <=> np > nl; nl = ~0 parks it), cnt = symbols decoded.  All NS window fetches are

@@ -700,16 +700,18 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     const uint32_t tail = total - full;  // < 16: bytes that wait for the next chunk (still byte ^ z)
                     uint8_t tv = 0;
                     if ((uint32_t)tid < tail) tv = ob[full + tid];
-                    __syncthreads();
-                    if (full > 0u) {
+                    if (full > 0u && tid < 64) {  // (tail < 16: the first wave alone; LDS keeps one wave's operations in order)
+                        wave_lds_fence();
                         if (tid < 4) L.tile[(full >> 2) + (uint32_t)tid] = 0u;
-                        if ((uint32_t)tid < tail) ob[tid] = tv;
                     }
+                    __syncthreads();
+                    // the carry lands in front of everything the next chunk's entries can touch (they start at byte `tail`):
+                    // no barrier between this and the next chunk's entries
+                    if (full > 0u && (uint32_t)tid < tail) ob[tid] = tv;
                     gpos += full;
                     ocarry = tail;
                     if (full > 0u) hskip = 0;
                     cbase = cend;
-                    __syncthreads();
                 }
             } else {
                 // ---- a list ran over (more than DFA_PCAP symbols other than z in one subsequence): this window goes to
