@@ -485,7 +485,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         for (int l = 33; l < 40; l++) L.lim[l] = L.lim[32];
         L.maxlen = mx;
 #if DCZ_K4_MEDIUM_DFA
-        if constexpr (CMASK == 2 && (MODE == 0 || MODE == 3)) {
+        if constexpr (CMASK == 2 && MODE != 1) {  // (the probe too: k4_dfa gives a block up by itself)
             // blocks the nibble automaton takes (k4_dfa.hip applies the same test to the same table): no 1-bit codeword
             // and at most 255 internal nodes in the code tree; this kernel keeps the rest of the medium class
             uint32_t ni = 0, states = 0;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(W, MODE == 3 ? 4 : (W <= 256 && !MULTI) ? (PV <= 48
         return;
     }
 #if DCZ_K4_MEDIUM_DFA
-    if constexpr (CMASK == 2 && (MODE == 0 || MODE == 3)) {
+    if constexpr (CMASK == 2 && MODE != 1) {  // (the probe too: k4_dfa gives a block up by itself)
         if (L.dfa_takes) return;  // workgroup-uniform
     }
 #endif
