@@ -45,18 +45,20 @@ namespace dcz {
 // The nibbles of subsequence dwords >= HOIST_DW are extracted where they are used, not once per window: the instantiations
 // that would spill otherwise (regions, 1024 threads) give up the last dword(s) -- a spill reload is a load, and on gfx950 a
 // load waits for every older store of the wave.
-#define DFA_FRESH(R) do { } while (0)
-#define DFA_FRESH1(r)                                            \
-    do {                                                         \
-        if constexpr ((j >> 3) >= HOIST_DW) asm volatile("" : "+v"(r)); \
-    } while (0)
-// the walks a recording instantiation only falls back to (count, output) extract every nibble where it is used: they must
-// not stretch the live ranges of the walks that count (a COPY is made opaque: the subsequence registers stay loop-invariant)
-#define DFA_FRESH_COPY(dst, r)                                    \
-    uint32_t dst = (r);                                           \
-    do {                                                          \
-        if constexpr (RECORD || SPARSE) asm volatile("" : "+v"(dst)); \
-    } while (0)
+// The nibble offsets of a subsequence dword are loop-invariant, so the compiler computes them once per window and keeps
+// them in registers (DCZ_DFA_HOIST).  Where that must not happen -- dwords >= HOIST_DW, and every dword of the walks a
+// recording instantiation only falls back to -- a step takes its dword from DFA_RJ: a COPY the compiler cannot see through,
+// made when the walk reaches the dword.  The subsequence registers R themselves are never touched: an earlier form marked
+// R[k] itself as modified ("+v"(R[k])), which made R loop-carried through every walk of the round loop, and two builds of
+// this kernel then re-recorded the last symbols of a subsequence from a different dword 7 in repair rounds (same source,
+// different register shuffles; found by a fuzz case, tools/dbg_stress.py).
+#define DFA_RJ_DECL uint32_t rfresh_ = 0
+#define DFA_RJ(rj, ALWAYS)                                                     \
+    if constexpr ((j & 7) == 0 && ((ALWAYS) || (j >> 3) >= HOIST_DW)) {        \
+        rfresh_ = R[j >> 3];                                                   \
+        asm volatile("" : "+v"(rfresh_));                                      \
+    }                                                                          \
+    const uint32_t rj = ((ALWAYS) || (j >> 3) >= HOIST_DW) ? rfresh_ : R[j >> 3]
 #ifndef DCZ_DFA_HOIST_DW_SPLIT
 #define DCZ_DFA_HOIST_DW_SPLIT 3
 #endif
@@ -75,6 +77,15 @@ namespace dcz {
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
+#ifndef DCZ_DFA_DBG_H
+#define DCZ_DFA_DBG_H 0
+#endif
+#ifndef DCZ_DFA_DBG
+#define DCZ_DFA_DBG 0
+#endif
+#ifndef DCZ_DFA_X6
+#define DCZ_DFA_X6 1  // exit-only walk in 6-bit steps for code trees of <= 127 internal nodes (0: nibbles always)
+#endif
 #ifndef DCZ_DFA_RECORD
 #define DCZ_DFA_RECORD 1  // 1: two walks per subsequence (exit-only, then ONE walk that counts AND records the symbols in a
 #endif                    // private LDS slot; the slots are closed up in place); 0: three walks (exit-only, count, output)
@@ -166,6 +177,9 @@ __device__ __forceinline__ uint4 dfa_shift(const uint4& a, const uint4& b, uint3
                       __builtin_amdgcn_alignbyte(d[Q + 3], d[Q + 2], r), __builtin_amdgcn_alignbyte(d[Q + 4], d[Q + 3], r));
 }
 
+#if DCZ_DFA_DBG
+__device__ unsigned long long dfa_dbg[8];  // debugging (tools/dbg_split.py)
+#endif
 #if DCZ_K4_PROF
 __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] flushes
 #define DFA_T(i)                                  \
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     constexpr bool SPLIT = MODE == 1, COUNT = MODE == 2;
     constexpr bool RECORD = OC < 0;  // the walk that counts also records the symbols (DfaLds: the slot area is the tile)
     static_assert(!RECORD || (!SPARSE && !COUNT), "only the decoding passes of the dense automaton record");
-    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : (OC < 0 || SPARSE) ? DCZ_DFA_HOIST_DW_REC : 8;
+    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : COUNT ? 8 : DCZ_DFA_HOIST_DW_REC;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -306,6 +320,13 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     } else {
         if (L.cnt[1] != 0u || L.nstates > 255u || L.maxlen == 0u) return;
     }
+    // Code trees of at most 127 internal nodes (text: 96) leave the upper half of T unused: it holds a second table for the
+    // exit-only walk, X6[state][6 bits] = next state (one byte), and that walk takes 32 steps of 6 bits instead of 48
+    // nibbles.  The error state of such a block is 127 instead of 255 (block-uniform).
+    constexpr bool X6_OK = DCZ_DFA_X6 && !SPARSE && !COUNT;  // (the counting pass keeps the nibbles: its registers are full;
+    const bool small = X6_OK && L.nstates <= 127u;           //  state numbers are the same either way)
+    const uint32_t errst = small ? 127u : DFA_ERR;
+    const uint32_t trows = small ? 128u : 256u;
     for (int sy = tid; sy < 256; sy += W) {
         const uint32_t l = L.len8[sy];
         if (l > 0) {
@@ -322,9 +343,9 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     }
     __syncthreads();
     if (tid == 0) L.zsym = L.symtab[0];  // the first canonical symbol (symtab shares its memory with the tile)
-    for (uint32_t idx = (uint32_t)tid; idx < 256u * 16u; idx += W) {
+    for (uint32_t idx = (uint32_t)tid; idx < trows * 16u; idx += W) {
         const uint32_t st = idx >> 4, nib = idx & 15u;
-        uint32_t e = DFA_ERR << 6;  // unused rows and the error state: stay in the error state
+        uint32_t e = errst << 6;  // unused rows and the error state: stay in the error state
         if (st < L.nstates) {
             uint32_t l = L.node_l[st], p = L.node_p[st], c = 0, syms = 0;
             uint32_t nz = 0, pos = 0;  // SPARSE: symbols other than z and the index of the last one
@@ -358,11 +379,39 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             }
             // (a nibble that leaves the code tree still counts the symbols it completed before: the reference's error
             // position is the number of symbols decoded so far)
-            const uint32_t next = err ? DFA_ERR : L.base[l] + (p - L.first[l] - L.cnt[l]);
+            const uint32_t next = err ? errst : L.base[l] + (p - L.first[l] - L.cnt[l]);
             if constexpr (SPARSE) e = c | (nz << 3) | (next << 6) | (pos << 14) | (syms << 16);
             else e = (next << 6) | c | (c << 3) | (syms << 16);
         }
         L.T[idx] = e;
+    }
+    if (small) {  // X6: the state six bits on (symbols do not matter to the exit-only walk)
+        uint8_t* const x6 = reinterpret_cast<uint8_t*>(&L.T[128 * 16]);
+        for (uint32_t idx = (uint32_t)tid; idx < 128u * 64u; idx += W) {
+            const uint32_t st = idx >> 6, v = idx & 63u;
+            uint32_t next = errst;
+            if (st < L.nstates) {
+                uint32_t l = L.node_l[st], p = L.node_p[st];
+                bool err = false;
+                for (int i = 5; i >= 0 && !err; i--) {
+                    p = 2u * p + ((v >> i) & 1u);
+                    l++;
+                    if (l > 32u) {
+                        err = true;
+                        break;
+                    }
+                    const uint32_t rel = p - L.first[l];
+                    if (rel < L.cnt[l]) {  // a leaf: the codeword is complete
+                        l = 0;
+                        p = 0;
+                    } else if (rel - L.cnt[l] >= L.nint[l]) {
+                        err = true;  // no codeword has this prefix (incomplete code)
+                    }
+                }
+                if (!err) next = L.base[l] + (p - L.first[l] - L.cnt[l]);
+            }
+            x6[idx] = (uint8_t)next;
+        }
     }
     const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.T[0]));
     const uint32_t tile_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)(&L.tile[0]));
@@ -476,14 +525,32 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         while (true) {
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
                 uint32_t e = g << 6, n = 0;
-                DFA_FRESH(R);
-                if (round == 0u) {  // workgroup-uniform
+                if (round == 0u && small) {  // workgroup-uniform: 32 steps of six bits over the last 192 bits
+                    uint32_t rq[8], st6 = 0;  // (copies the compiler cannot see through: nothing of this walk is kept in
+#pragma unroll                                //  registers across the rounds, unlike the nibble offsets)
+                    for (int k = 2; k < 8; k++) {
+                        rq[k] = R[k];
+                        asm volatile("" : "+v"(rq[k]));
+                    }
+                    auto stepX6 = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int pbit = 64 + 6 * decltype(ic)::value, k = pbit >> 5, off = pbit & 31;
+                        uint32_t v;
+                        if constexpr (off <= 26) v = (rq[k] >> (26 - off)) & 63u;
+                        else v = __builtin_amdgcn_alignbit(rq[k], rq[k < 7 ? k + 1 : 7], 58 - off) & 63u;
+                        st6 = (uint32_t)*(const lds_u8*)(uintptr_t)(t_addr + 8192u + ((st6 << 6) | v));
+                    };
+                    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                        (stepX6(std::integral_constant<int, Is>{}), ...);
+                    }(std::make_integer_sequence<int, 32>{});
+                    e = st6 << 6;
+                } else if (round == 0u) {  // workgroup-uniform
                     if (DCZ_DFA_X_FROM > 0) e = 0;  // (mid-subsequence every lane guesses "codeword boundary")
+                    DFA_RJ_DECL;
                     auto stepX = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);  // nibble j of the dword, as a byte offset of a u32 entry
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        DFA_RJ(rj, false);
+                        const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                     };
                     // The guess only has to be right often: the walk covers the subsequence's last 64 - DCZ_DFA_X_FROM
@@ -497,11 +564,12 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     // into the lane's list.  The entry is stored every step and the list pointer moves on only when the
                     // nibble had such a symbol; two in one nibble (1 step in 10^4 on 1 % noise) take the branch.
                     uint32_t pa = pl_addr;
+                    DFA_RJ_DECL;
                     auto stepP = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib4 = sh >= 0 ? ((R[j >> 3] >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        DFA_RJ(rj, false);
+                        const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                         const uint32_t oth = e & 0x18u;  // 8 * symbols other than z
                         const uint32_t tp = n + ((e >> 14) & 3u);
@@ -525,12 +593,13 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     // private slot every time (a plain store: nobody else writes there); when it is full the spill-over
                     // becomes the next dword.  The count is the fill level at the end.
                     uint32_t ab = slot_addr, k8 = 0, alo = 0;
+                    DFA_RJ_DECL;
                     auto stepR = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = 2 * decltype(jc)::value;
                         constexpr int sh0 = 26 - 4 * (j & 7), sh1 = 26 - 4 * ((j + 1) & 7);
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        const uint32_t nib0 = (R[j >> 3] >> sh0) & 0x3Cu;
-                        const uint32_t nib1 = sh1 >= 0 ? ((R[j >> 3] >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((R[j >> 3] << 2) & 0x3Cu);
+                        DFA_RJ(rj, false);
+                        const uint32_t nib0 = (rj >> sh0) & 0x3Cu;
+                        const uint32_t nib1 = sh1 >= 0 ? ((rj >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib0));
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e0 & AMASK) | nib1));
                         const uint32_t c0 = e0 & 0x18u;  // 8 * symbols of the first nibble (bytes past the count are zero)
@@ -549,12 +618,15 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     }(std::make_integer_sequence<int, 32>{});
                     *(lds_u32*)(uintptr_t)ab = alo;  // (the dword under construction; at most slot byte 128..131)
                     n = (ab - slot_addr) + (k8 >> 3);
+#if DCZ_DFA_DBG
+                    *(lds_u32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u) = n | (round << 8) | ((need ? 1u : 0u) << 16) | (g << 24);
+#endif
                 } else {
+                    DFA_RJ_DECL;
                     auto stepA = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        DFA_FRESH_COPY(rj, R[j >> 3]);
+                        DFA_RJ(rj, RECORD || SPARSE);
                         const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                         n += e & (SPARSE ? 7u : 3u);
@@ -598,7 +670,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         }
 
         // ---- offsets, errors ----
-        const bool bad = !beyond && x == DFA_ERR;
+        const bool bad = !beyond && x == errst;
         uint32_t tw = 0;
         // (RECORD with small slots: a subsequence that ran over its slot rides along in bit 20 of the scanned value -- the
         // counts of a window add up to < 2^16 -- so the window learns about it without another barrier)
@@ -740,11 +812,11 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     uint32_t e = g << 6;
                     uint32_t t = o;
                     const uint32_t cmask = mine ? 7u : 0u, zmask = mine ? 0x18u : 0u;  // switched-off lanes store nothing
+                    DFA_RJ_DECL;
                     auto stepS = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int sh = 26 - 4 * (j & 7);
-                        if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                        DFA_FRESH_COPY(rj, R[j >> 3]);
+                        DFA_RJ(rj, RECORD || SPARSE);
                         const uint32_t nib4 = sh >= 0 ? ((rj >> (sh >= 0 ? sh : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                         e = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib4));
                         const uint32_t nz = e & zmask;
@@ -790,6 +862,20 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             // share their dwords with the neighbours and go out as single bytes.
             const uint32_t take = (o < lim) ? ((nsym < lim - o) ? nsym : lim - o) : 0u;
             const uint32_t dpos = ocarry + o;
+#if DCZ_DFA_DBG
+            {
+                const uint32_t stamp = *(lds_cu32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u);
+                if (!beyond && nsym > 0u) {
+                    atomicAdd(&dfa_dbg[0], 1ull);
+                    if ((stamp & 0xFFu) != (nsym & 0xFFu)) {
+                        atomicAdd(&dfa_dbg[1], 1ull);
+                        dfa_dbg[2] = ((unsigned long long)stamp << 32) | (nsym | (g << 24));  // last offender
+                    }
+                    if (((stamp >> 24) & 0xFFu) != (g & 0xFFu)) atomicAdd(&dfa_dbg[3], 1ull);
+                    if (((stamp >> 8) & 0xFFu) > 1u) atomicAdd(&dfa_dbg[4], 1ull);  // slot last written in a repair round
+                }
+            }
+#endif
             uint32_t hb = (4u - (dpos & 3u)) & 3u;
             if (hb > take) hb = take;
             const uint32_t nd = (take - hb) >> 2, tb = (take - hb) & 3u, shb = hb << 3;
@@ -799,7 +885,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     constexpr int q = Qs;
                     w[2 * q] = 0;
                     w[2 * q + 1] = 0;
-                    if (__builtin_amdgcn_ballot_w64(take > 8u * (uint32_t)q) != 0ull) {  // wave-uniform
+                    if (DCZ_DFA_DBG_H == 3 || __builtin_amdgcn_ballot_w64(take > 8u * (uint32_t)q) != 0ull) {  // wave-uniform
                         const unsigned long long v2 =
                             *(__attribute__((address_space(3))) const unsigned long long*)(uintptr_t)(slot_addr + 8u * (uint32_t)q);
                         w[2 * q] = (uint32_t)v2;
@@ -815,6 +901,10 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                 tailv = __builtin_amdgcn_alignbit(t1, t0, shb);
             }
             __syncthreads();
+#if DCZ_DFA_DBG_H == 1
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+#endif
             {
                 typedef __attribute__((address_space(3))) uint8_t lds_u8;
                 const uint32_t dst = tile_addr + dpos, d4 = dst + hb;
@@ -885,7 +975,6 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             uint32_t ab = 0, k8 = 0, alo = 0;  // ab: LDS byte address of the dword being collected
             if (!(DCZ_DFA_ABL & 8) && __builtin_amdgcn_ballot_w64(mine) != 0ull) {
                 uint32_t e = g << 6;
-                DFA_FRESH(R);
                 const uint32_t p0 = mine ? o + tshift : 0u;
                 ab = tile_addr + (p0 & ~3u);
                 k8 = (p0 & 3u) << 3;
@@ -893,11 +982,11 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                 // (the first lane of a flush continues the bytes the flush before left in the tile)
                 if (mine && o == cbase) alo = *(lds_u32*)(uintptr_t)ab & ((1u << k8) - 1u);
                 const uint32_t tmask = mine ? 0x18u : 0u;  // switched-off lanes collect nothing
+                DFA_RJ_DECL;
                 auto stepB = [&](auto jc) __attribute__((always_inline)) {  // two nibbles: up to four symbols
                     constexpr int j = 2 * decltype(jc)::value;
                     constexpr int sh0 = 26 - 4 * (j & 7), sh1 = 26 - 4 * ((j + 1) & 7);
-                    if constexpr ((j & 7) == 0) DFA_FRESH1(R[j >> 3]);
-                    DFA_FRESH_COPY(rj, R[j >> 3]);
+                    DFA_RJ(rj, RECORD || SPARSE);
                     const uint32_t nib0 = (rj >> sh0) & 0x3Cu;
                     const uint32_t nib1 = sh1 >= 0 ? ((rj >> (sh1 >= 0 ? sh1 : 0)) & 0x3Cu) : ((rj << 2) & 0x3Cu);
                     const uint32_t e0 = *(lds_cu32*)(uintptr_t)(t_addr + ((e & AMASK) | nib0));
@@ -985,7 +1074,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                         break;
                     }
                     st = (e >> 6) & 0xFFu;
-                    if (st == DFA_ERR) {
+                    if (st == errst) {
                         status = DCZ_E_BADSTREAM;
                         errpos = (long long)produced;
                         break;
@@ -1001,7 +1090,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
     if constexpr (COUNT) {
         if (tid == 0) {
             const uint64_t i = (uint64_t)b * sdp->rmax + reg;
-            const bool bad = unusable || wexit == DFA_ERR || rentry == DFA_ERR;
+            const bool bad = unusable || wexit == errst || rentry == errst;
             sdp->entry[i] = rentry;
             sdp->count[i] = (uint32_t)(rcount > 0xFFFFFFFFull ? 0xFFFFFFFFull : rcount);
             sdp->exit[i] = bad ? 0xFFFFFFFFu : wexit;
@@ -1060,6 +1149,15 @@ void launch_decode_dfa(const uint8_t* d_comp, const uint64_t* d_comp_off, const 
 
 }  // namespace dcz
 
+#if DCZ_DFA_DBG
+extern "C" void dcz_debug_dfa_dbg(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::dfa_dbg), sizeof(dcz::dfa_dbg));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(dcz::dfa_dbg), z, sizeof(z));
+    }
+}
+#endif
 #if DCZ_K4_PROF
 extern "C" void dcz_debug_dfa_prof(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(dcz::dfa_prof), sizeof(dcz::dfa_prof));

@@ -22,5 +22,12 @@ for seed in [int(a) for a in sys.argv[2:]]:
             if detail is None and bad.size:
                 b = int(bad[0]) // bb
                 bi = bad[bad // bb == b] - b * bb
-                detail = "block %d csize %d bad bytes %s" % (b, sizes[b], bi[:12].tolist())
+                detail = "block %d csize %d bad bytes %s\n   got  %s\n   want %s" % (b, sizes[b], bi[:16].tolist(), dec[b * bb + bi[:16]].tolist(), data[b * bb + bi[:16]].tolist())
+                l = lens[b]
+                ends = np.cumsum(l[data[b * bb:(b + 1) * bb]].astype(np.int64))
+                o = np.concatenate([[0], np.cumsum(np.bincount((ends - 1) // 256))])
+                detail += "\n   lane starts %s" % o[:12].tolist()
+                # what the same positions hold in the neighbourhood (is it a shifted copy?)
+                x = int(bi[0])
+                detail += "\n   around first bad: got %s want %s" % (dec[b * bb + x - 6:b * bb + x + 6].tolist(), data[b * bb + x - 6:b * bb + x + 6].tolist())
     print("seed", seed, "K", sizes.size, "bb", bb, "fails %d/%d" % (fails, reps), "bad bytes", nbad, detail or "", flush=True)
