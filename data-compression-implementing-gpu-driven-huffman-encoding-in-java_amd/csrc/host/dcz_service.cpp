@@ -816,10 +816,21 @@ void compressSharded(const std::string& inputPath, const std::string& outputPath
         header.originalFileSize = size;
         header.originalTimestamp = (int64_t)st.st_mtim.tv_sec * 1000 + st.st_mtim.tv_nsec / 1000000;
         header.chunkSizeBytes = (int32_t)cb;
-        std::ofstream fout(outputPath, std::ios::binary | std::ios::trunc);
-        if (!fout) throw IOError("Cannot open " + outputPath);
+        const int ofd = ::open(outputPath.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (ofd < 0) throw IOError("Cannot open " + outputPath);
+        auto write_all = [&](const uint8_t* p, size_t n) {
+            while (n > 0) {
+                const ssize_t w = ::write(ofd, p, n);
+                if (w <= 0) {
+                    ::close(ofd);
+                    throw IOError("Cannot write " + outputPath);
+                }
+                p += w;
+                n -= (size_t)w;
+            }
+        };
         int64_t base = 0;
-        std::vector<uint8_t> digests, buf((size_t)8 << 20);
+        std::vector<uint8_t> digests, buf;
         for (size_t r = 0; r < plan.size(); r++) {
             int64_t mine = 0;
             for (ChunkMetadata c : svc[r]->shardChunks()) {
@@ -828,23 +839,40 @@ void compressSharded(const std::string& inputPath, const std::string& outputPath
                 digests.insert(digests.end(), c.sha256, c.sha256 + 32);
                 header.chunks.push_back(c);
             }
-            std::ifstream pin(part(r), std::ios::binary);
+            // the rank's payload span follows the spans of the ranks before it: copied inside the kernel
+            // (copy_file_range: no pass through user space), by read + write where the file systems do not allow that
+            const int ifd = ::open(part(r).c_str(), O_RDONLY);
+            if (ifd < 0) {
+                ::close(ofd);
+                throw IOError("Cannot read " + part(r));
+            }
             int64_t left = mine;
             while (left > 0) {
-                const std::streamsize n = (std::streamsize)std::min<int64_t>(left, (int64_t)buf.size());
-                if (!pin.read(reinterpret_cast<char*>(buf.data()), n)) throw IOError("Cannot read " + part(r));
-                fout.write(reinterpret_cast<const char*>(buf.data()), n);
+                const ssize_t c = ::copy_file_range(ifd, nullptr, ofd, nullptr, (size_t)left, 0);
+                if (c <= 0) break;
+                left -= c;
+            }
+            while (left > 0) {
+                if (buf.empty()) buf.resize((size_t)8 << 20);
+                const ssize_t n = ::read(ifd, buf.data(), (size_t)std::min<int64_t>(left, (int64_t)buf.size()));
+                if (n <= 0) {
+                    ::close(ifd);
+                    ::close(ofd);
+                    throw IOError("Cannot read " + part(r));
+                }
+                write_all(buf.data(), (size_t)n);
                 left -= n;
             }
+            ::close(ifd);
             base += mine;
         }
         sha256(digests.data(), digests.size(), header.globalChecksum);
         const std::vector<uint8_t> hb = header.write();
-        fout.write(reinterpret_cast<const char*>(hb.data()), (std::streamsize)hb.size());
+        write_all(hb.data(), hb.size());
         BeWriter ptr;
         ptr.i64(base);
-        fout.write(reinterpret_cast<const char*>(ptr.b.data()), 8);
-        if (!fout) throw IOError("Cannot write " + outputPath);
+        write_all(ptr.b.data(), 8);
+        if (::close(ofd) != 0) throw IOError("Cannot write " + outputPath);
         if (metrics) {
             *metrics = StageMetrics();
             for (auto& s : svc) metrics->merge(s->getLastStageMetrics());
