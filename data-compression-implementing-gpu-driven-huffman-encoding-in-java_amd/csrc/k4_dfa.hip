@@ -77,9 +77,6 @@ namespace dcz {
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
-#ifndef DCZ_DFA_DBG_H
-#define DCZ_DFA_DBG_H 0
-#endif
 #ifndef DCZ_DFA_DBG
 #define DCZ_DFA_DBG 0
 #endif
@@ -178,7 +175,8 @@ __device__ __forceinline__ uint4 dfa_shift(const uint4& a, const uint4& b, uint3
 }
 
 #if DCZ_DFA_DBG
-__device__ unsigned long long dfa_dbg[8];  // debugging (tools/dbg_split.py)
+__device__ unsigned long long dfa_dbg[8];  // debugging (-DDCZ_DFA_DBG=1, tools/dbg_split.py): the walk stamps count and
+                                            // byte checksum into its slot, the compaction compares what it is about to copy
 #endif
 #if DCZ_K4_PROF
 __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] flushes
@@ -593,6 +591,9 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     // private slot every time (a plain store: nobody else writes there); when it is full the spill-over
                     // becomes the next dword.  The count is the fill level at the end.
                     uint32_t ab = slot_addr, k8 = 0, alo = 0;
+#if DCZ_DFA_DBG
+                    uint32_t chk = 0;  // sum of the recorded symbol bytes
+#endif
                     DFA_RJ_DECL;
                     auto stepR = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = 2 * decltype(jc)::value;
@@ -605,6 +606,9 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                         const uint32_t c0 = e0 & 0x18u;  // 8 * symbols of the first nibble (bytes past the count are zero)
                         const uint32_t w = ((e >> 16) << c0) | (e0 >> 16);
                         const unsigned long long v = (unsigned long long)w << k8;
+#if DCZ_DFA_DBG
+                        chk = __builtin_amdgcn_sad_u8(w, 0u, chk);
+#endif
                         alo |= (uint32_t)v;
                         *(lds_u32*)(uintptr_t)ab = alo;
                         k8 += c0 + (e & 0x18u);
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     *(lds_u32*)(uintptr_t)ab = alo;  // (the dword under construction; at most slot byte 128..131)
                     n = (ab - slot_addr) + (k8 >> 3);
 #if DCZ_DFA_DBG
-                    *(lds_u32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u) = n | (round << 8) | ((need ? 1u : 0u) << 16) | (g << 24);
+                    *(lds_u32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u) = (n & 0xFFu) | (chk << 8);
 #endif
                 } else {
                     DFA_RJ_DECL;
@@ -862,20 +866,6 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             // share their dwords with the neighbours and go out as single bytes.
             const uint32_t take = (o < lim) ? ((nsym < lim - o) ? nsym : lim - o) : 0u;
             const uint32_t dpos = ocarry + o;
-#if DCZ_DFA_DBG
-            {
-                const uint32_t stamp = *(lds_cu32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u);
-                if (!beyond && nsym > 0u) {
-                    atomicAdd(&dfa_dbg[0], 1ull);
-                    if ((stamp & 0xFFu) != (nsym & 0xFFu)) {
-                        atomicAdd(&dfa_dbg[1], 1ull);
-                        dfa_dbg[2] = ((unsigned long long)stamp << 32) | (nsym | (g << 24));  // last offender
-                    }
-                    if (((stamp >> 24) & 0xFFu) != (g & 0xFFu)) atomicAdd(&dfa_dbg[3], 1ull);
-                    if (((stamp >> 8) & 0xFFu) > 1u) atomicAdd(&dfa_dbg[4], 1ull);  // slot last written in a repair round
-                }
-            }
-#endif
             uint32_t hb = (4u - (dpos & 3u)) & 3u;
             if (hb > take) hb = take;
             const uint32_t nd = (take - hb) >> 2, tb = (take - hb) & 3u, shb = hb << 3;
@@ -885,7 +875,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     constexpr int q = Qs;
                     w[2 * q] = 0;
                     w[2 * q + 1] = 0;
-                    if (DCZ_DFA_DBG_H == 3 || __builtin_amdgcn_ballot_w64(take > 8u * (uint32_t)q) != 0ull) {  // wave-uniform
+                    if (__builtin_amdgcn_ballot_w64(take > 8u * (uint32_t)q) != 0ull) {  // wave-uniform
                         const unsigned long long v2 =
                             *(__attribute__((address_space(3))) const unsigned long long*)(uintptr_t)(slot_addr + 8u * (uint32_t)q);
                         w[2 * q] = (uint32_t)v2;
@@ -894,6 +884,26 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                 }(), ...);
             }(std::make_integer_sequence<int, 16>{});
             w[32] = 0;
+#if DCZ_DFA_DBG
+            {   // the bytes the compaction is about to copy against what the walk that wrote the slot said it recorded
+                const uint32_t stamp = *(lds_cu32*)(uintptr_t)(slot_addr + (uint32_t)dfa_slot(W) - 4u);
+                if (!beyond && nsym > 0u && take == nsym) {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int k = 0; k < 32; k++) {
+                        const uint32_t have = take > 4u * (uint32_t)k ? take - 4u * (uint32_t)k : 0u;  // bytes of dword k that count
+                        const uint32_t m = have >= 4u ? 0xFFFFFFFFu : ((1u << (8u * have)) - 1u);
+                        sum = __builtin_amdgcn_sad_u8(w[k] & m, 0u, sum);
+                    }
+                    atomicAdd(&dfa_dbg[0], 1ull);
+                    if ((stamp & 0xFFu) != (nsym & 0xFFu)) atomicAdd(&dfa_dbg[1], 1ull);
+                    if ((stamp >> 8) != (sum & 0xFFFFFFu)) {
+                        atomicAdd(&dfa_dbg[3], 1ull);
+                        dfa_dbg[2] = ((unsigned long long)stamp << 32) | (sum << 8) | (nsym & 0xFFu);
+                    }
+                }
+            }
+#endif
             uint32_t tailv;
             {
                 const uint32_t t0 = *(lds_cu32*)(uintptr_t)(slot_addr + 4u * nd);
@@ -901,10 +911,6 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                 tailv = __builtin_amdgcn_alignbit(t1, t0, shb);
             }
             __syncthreads();
-#if DCZ_DFA_DBG_H == 1
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-#endif
             {
                 typedef __attribute__((address_space(3))) uint8_t lds_u8;
                 const uint32_t dst = tile_addr + dpos, d4 = dst + hb;

@@ -21,8 +21,8 @@ if hasattr(pkg.lib(), "dcz_debug_dfa_dbg"):
     f.argtypes = [ctypes.c_void_p, ctypes.c_int]
     buf = (ctypes.c_ulonglong * 8)()
     f(buf, 1)
-    print("dbg: lanes %d, stamp.n != nsym %d (last: stamp %08x nsym|g %08x), stamp.g != g %d, last written in a repair round %d" % (
-        buf[0], buf[1], buf[2] >> 32, buf[2] & 0xFFFFFFFF, buf[3], buf[4]))
+    print("dbg: lanes %d, stamp.n != nsym %d, checksum(walk) != checksum(slot at compaction) %d (last: stamp %08x slot %08x)" % (
+        buf[0], buf[1], buf[3], buf[2] >> 32, buf[2] & 0xFFFFFFFF))
 print("n MiB", n >> 20, "regions of 64 KiB ~", int(blk.comp_size[0]) >> 16)
 print("status", st.cpu().numpy()[:1], "payload", int(blk.comp_size[0]), "mismatches", bad.size)
 if bad.size:
