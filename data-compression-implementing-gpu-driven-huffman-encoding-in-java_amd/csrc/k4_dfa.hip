@@ -72,8 +72,8 @@ namespace dcz {
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
 #ifndef DCZ_DFA_SPARSE_OC
-#define DCZ_DFA_SPARSE_OC 13312  // SPARSE: bytes of output composed per chunk (a window is ~60 KiB of output): what four workgroups
-#endif                           // per CU leave after the table (16 KiB) and the lists (8.6 KiB)
+#define DCZ_DFA_SPARSE_OC 16384  // SPARSE: bytes of output composed per chunk (a window is ~60 KiB of output): what four workgroups
+#endif                           // per CU leave after the table (16 KiB) and the lists (6.8 KiB)
 #ifndef DCZ_DFA_ABL
 #define DCZ_DFA_ABL 0  // timing ablations (WRONG output; tools/run_variants.sh --no-verify): 2 = no phase B stores,
 #endif                 // 4 = no exit-only round, 8 = no phase B walk at all, 16 = one round only
@@ -120,9 +120,13 @@ constexpr uint32_t DFA_ERR = 255;  // sticky state: the stream left the code tre
 #endif
 constexpr int dfa_slot(int W) { return W > 512 ? 136 : DCZ_DFA_SLOT_SMALL; }
 // SPARSE: the walk that counts records the symbols other than z as (position inside the subsequence, byte) pairs of 16 bits in
-// a per-lane list of DFA_PCAP entries (+ 1: the entry under construction); the window's output is then composed in LDS,
+// a per-lane list of DFA_PCAP (12) entries (+ 1: the entry under construction); the window's output is then composed in LDS,
 // chunk by chunk, and written ONCE (PL > 0: the tile is a chunk of OC bytes).
-constexpr int DFA_PCAP = 16;
+#ifndef DCZ_DFA_PCAP
+#define DCZ_DFA_PCAP 12  // (16 with a 13 KiB chunk tile: 2.85 ms on config 5's slice; 12 with 16 KiB: 2.70; 10 with 18 KiB does not
+                         //  fit four workgroups per CU any more: 3.44)
+#endif
+constexpr int DFA_PCAP = DCZ_DFA_PCAP;
 template <int W, int OC, int PL = 0>
 struct DfaLds {
     // tile capacity of the output walk (its last lane may run 300 bytes past the end of a flush); OC < 0: the slot area
@@ -518,6 +522,9 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         // here too); later rounds (rare) re-walk the lanes whose entry still changed.
         uint32_t g = (tid == 0) ? entry0 : 0u;  // entry state
         uint32_t x = 0, nsym = 0, pc = 0;  // pc (SPARSE): symbols other than z this lane has recorded
+        bool pover = false;  // some walk of this lane ran over its list (SPARSE) or slot (RECORD) -- in ANY round: a walk from a wrong
+                             // entry state that runs over scribbles on the lists / slots of lanes in the NEXT wave, which may not
+                             // walk again when this lane does (its exit can be the same after all)
         bool need = !beyond;
         uint32_t round = (DCZ_DFA_ABL & 4) ? 1u : 0u;
         while (true) {
@@ -642,6 +649,8 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                 if (need) {
                     x = (e >> 6) & 0xFFu;
                     nsym = n;
+                    if constexpr (SPARSE) pover |= pc > (uint32_t)DFA_PCAP;
+                    else if constexpr (RECORD) pover |= n > (uint32_t)dfa_slot(W) - 8u;
                 }
             }
             DFA_T(2);
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         // counts of a window add up to < 2^16 -- so the window learns about it without another barrier)
         constexpr uint32_t SLOT_SYMS = RECORD ? (uint32_t)dfa_slot(W) - 8u : 0u;
         constexpr bool SLOT_CHECK = (RECORD && SLOT_SYMS < 128u) || SPARSE;
-        const bool ran_over = !beyond && (SPARSE ? pc > (uint32_t)DFA_PCAP : nsym > SLOT_SYMS);
+        const bool ran_over = !beyond && pover;
         uint32_t o = dfa_block_scan<W>(nsym + ((SLOT_CHECK && ran_over) ? (1u << 20) : 0u), L, tw);
         const bool slot_ran_over = SLOT_CHECK && (tw >> 20) != 0u;
         if constexpr (SLOT_CHECK) {

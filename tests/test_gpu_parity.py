@@ -1386,7 +1386,7 @@ def test_sparse_class_tables_and_damage_against_the_oracle(pkg, svc, orc, shape,
 
 @pytest.mark.parametrize("shape", ["many_blocks", "few_blocks"])
 def test_sparse_windows_composed_in_lds_and_windows_whose_lists_run_over(pkg, svc, orc, shape):
-    """k4_dfa's SPARSE instantiation records the symbols other than the 1-bit one in per-lane lists of 16 entries and
+    """k4_dfa's SPARSE instantiation records the symbols other than the 1-bit one in per-lane lists of 12 entries and
     composes the window's output in LDS, written once; a window in which a list runs over is filled and patched in global
     memory instead.  Zero pages with 1 % noise and bursts of 30 % noise: both kinds of window, in either order, with the
     16-byte carry between them, in both launch shapes."""

@@ -1,8 +1,18 @@
 #!/bin/bash
-# full GPU suite + the driver's command (default bench run with secondary workloads)
+# full GPU suite + the driver's command (default bench run with secondary workloads).  If the suite dies on a GPU exception,
+# rocgdb reads the GPU core dump (kernel, pc, instruction of the wave that took it) into gpurun_out/diag_rocgdb.txt.
 R=$GRAFT_REPO_ROOT; cd $R
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3_tests.log 2>&1; rc=$?; echo "full tests rc=$rc"; tail -3 gpurun_out/r3_tests.log
-[ $rc -eq 0 ] || exit $rc
+rm -f gpucore.*
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q -s > gpurun_out/r3_tests.log 2>&1; rc=$?; echo "full tests rc=$rc"; tail -3 gpurun_out/r3_tests.log
+if [ $rc -ne 0 ]; then
+  c=$(ls gpucore.* 2>/dev/null | head -1)
+  if [ -n "$c" ]; then
+    timeout -k 10 300 /opt/rocm/bin/rocgdb -batch -ex "set pagination off" -ex "info agents" -ex "info dispatches" -ex "info threads" \
+        -ex "bt" -ex "info registers pc exec" -ex "x/12i \$pc-24" -ex "info registers" $(which python3) -c $c > gpurun_out/diag_rocgdb.txt 2>&1
+    grep -n "fault\|xception\|signal\|SIG\|k4_\|dcz" gpurun_out/diag_rocgdb.txt | head -40
+  fi
+  exit $rc
+fi
 timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; python3 - <<'PY'
 import json
 d=json.load(open('gpurun_out/r3_bench_default.json'))
