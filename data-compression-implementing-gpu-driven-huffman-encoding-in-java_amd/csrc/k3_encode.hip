@@ -33,6 +33,9 @@ namespace dcz {
 #ifndef DCZ_K3_COPIES
 #define DCZ_K3_COPIES 8
 #endif
+#ifndef DCZ_K3_LAZY_FLUSH
+#define DCZ_K3_LAZY_FLUSH 1  // flush the ring only when the next step might not fit (0: after every step)
+#endif
 constexpr int K3_WAVES = DCZ_K3_WAVES;    // waves (= segments) per workgroup
 constexpr int K3_COPIES = DCZ_K3_COPIES;  // codebook replicas: 32 would be conflict-free, 8 (4 lanes per replica, a few
                                           // 2-way conflicts) leaves room for 6 workgroups per CU and measures ~10 % faster
@@ -330,6 +333,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
 
     if (!wide) {
         const uint32_t nchunks = (slen + 1023u) >> 10;
+        const uint32_t step_bits = 1024u * maxlen + 512u;  // (+ the partly flushed chunk in front and the slack dwords)
+        const uint32_t flush_at = DCZ_K3_LAZY_FLUSH && step_bits < RING_WORDS * 32u ? RING_WORDS * 32u - step_bits : 0u;
         uint4 cur = make_uint4(0, 0, 0, 0);
         {
             const int nb = (int)slen - lane * 16;
@@ -357,7 +362,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                 wave_lds_fence();
                 if (lane < 4) st.ring[lane] = 0u;
             }
-            ring_flush(st, (st.rpos >> 7) << 4, lane);
+            // The ring is flushed when the NEXT step could run into bytes that are still in it (a step adds at most
+            // 1024 codewords of maxlen bits), not after every step: a flush is two fences, a read, a store and a zeroing
+            // pass whose lanes are mostly idle when a step produced little (zero pages: 8 of 64).
+            if ((int)(st.rpos - 8u * st.rflush) > (int)flush_at) ring_flush(st, (st.rpos >> 7) << 4, lane);  // wave-uniform
             cur = nxt;
         }
     } else {
