@@ -108,12 +108,19 @@ def run_workload(env, name, steps, warmup, verify, per_gpu_override=0, chunk_ove
     derrpos = torch.zeros(k_local, dtype=torch.int64, device=dev)
     torch.cuda.synchronize(dev)
 
+    # The caller's stream: the steps run on one torch stream whose handle goes to the library as the C ABI's `stream`
+    # argument (kernels, the per-kernel hipEvents and -- at N > 1 -- the RCCL all-gather are all queued on it, in order).
+    # --service-stream: the Python mirror's default instead (its own stream, ordered with the caller's by two events per call).
+    ts = None if env.args.service_stream else torch.cuda.Stream(dev)
+    sh = None if ts is None else ts.cuda_stream
+
     def step():
-        svc.compress_device(t_in, chunk, out=blk)
-        if world > 1:  # the one real exchange step: per-chunk compressed sizes -> global payload offsets
-            env.sharding.gather_chunk_sizes(blk.comp_size, k_total)
-        svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, chunk, t_out=t_out,
-                              status=dstatus, errpos=derrpos)
+        with torch.cuda.stream(ts):
+            svc.compress_device(t_in, chunk, out=blk, stream=sh)
+            if world > 1:  # the one real exchange step: per-chunk compressed sizes -> global payload offsets
+                env.sharding.gather_chunk_sizes(blk.comp_size, k_total)
+            svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, chunk, t_out=t_out,
+                                  status=dstatus, errpos=derrpos, stream=sh)
 
     for _ in range(warmup):
         step()
@@ -306,6 +313,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="only the headline workload (profiling passes; the default run also times the other configs)")
+    ap.add_argument("--service-stream", action="store_true",
+                    help="launch on the Python service's own stream (two cross-stream events per call) instead of handing "
+                         "the caller's stream to the C ABI")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only exists "
                          "to rehearse the N>1 code path on a one-GPU box")

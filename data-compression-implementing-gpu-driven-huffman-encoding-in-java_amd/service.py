@@ -142,6 +142,11 @@ class HipCompressionService:
         if stream is not None:
             return stream, None
         cur = self.torch.cuda.current_stream(dev)
+        if cur.cuda_stream != 0:
+            # a stream of the caller's own: the kernels are queued on it like the caller's torch work, nothing to order
+            # (two cross-stream events per call cost config 3's step 0.36 -> 0.28 ms)
+            return cur.cuda_stream, None
+        # torch's default stream has handle 0, which the C ABI reads as "the context's stream": order the two by events
         self.stream.wait_stream(cur)
         return self.stream.cuda_stream, cur
 

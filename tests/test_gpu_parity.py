@@ -1031,6 +1031,32 @@ def test_torch_ops_and_kernels_are_ordered_without_host_sync(pkg, svc, orc):
         assert (offsets.cpu().numpy() == np.concatenate([[0], np.cumsum(want)[:-1]])).all()
 
 
+def test_kernels_run_on_the_callers_own_stream_in_program_order(pkg, svc, orc):
+    """A caller whose current torch stream is not the default one gets the kernels queued on THAT stream (no service
+    stream, no cross-stream events: what bench.py does): torch ops before and after a call see its tensors in program
+    order, a whole round trip included, with no host synchronisation in between."""
+    torch = _torch()
+    from dcz_amd import sharding
+    n, bb = 48 << 20, 1 << 20
+    t = _gen_device(pkg, svc, "text", n, seed=11)
+    want_sizes = svc.compress_device(t, bb).comp_size.clone()
+    torch.cuda.synchronize()
+    ts = torch.cuda.Stream()
+    ts.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ts):
+        assert svc._enter(None, t.device) == (ts.cuda_stream, None)
+        blk = svc.compress_device(t, bb)
+        orig = torch.full((blk.num_chunks,), bb, dtype=torch.int32, device="cuda")
+        for _ in range(4):
+            blk.comp_size.zero_()  # queued on ts: must land BEFORE the kernels rewrite the sizes
+            blk = svc.compress_device(t, bb, out=blk)
+            all_sizes, _, _ = sharding.gather_chunk_sizes(blk.comp_size, blk.num_chunks)
+            out, status, _ = svc.decompress_device(blk.payload, blk.comp_off, blk.comp_size, orig, blk.code_lengths, bb)
+            same = torch.equal(out[:n], t) and bool((status == 0).all().item()) and torch.equal(all_sizes.to(torch.int32), want_sizes)
+            assert same
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------------
 # Few large blocks: one block decoded by many workgroups (k4_split.hip: counting pass over regions, proven entries, the
 # table-walk kernels once per region).  The reference's own chunk sizes: 32 MiB (cli/DataCompCLI.java:35) and 16 MiB
