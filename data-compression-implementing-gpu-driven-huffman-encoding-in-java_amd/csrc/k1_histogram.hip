@@ -34,6 +34,9 @@ namespace dcz {
 #ifndef DCZ_K1_WAVES
 #define DCZ_K1_WAVES 4
 #endif
+#ifndef DCZ_K1_RUNS
+#define DCZ_K1_RUNS 1  // steps whose 16-byte units are mostly runs of one byte add 16 at a time (hist_add_vec_runs)
+#endif
 constexpr int K1_WAVES = DCZ_K1_WAVES;    // waves (= segments) per workgroup
 constexpr int K1_COPIES = DCZ_K1_COPIES;  // histogram replicas per wave: 32 = one per bank (conflict-free for any data)
 constexpr int K1_CSHIFT = (K1_COPIES == 32) ? 5 : (K1_COPIES == 16) ? 4 : 3;
@@ -73,6 +76,23 @@ __device__ __forceinline__ void hist_add_vec(uint32_t* h, uint32_t col, const ui
     hist_add_dword(h, col, v.y);
     hist_add_dword(h, col, v.z);
     hist_add_dword(h, col, v.w);
+}
+
+// Runs (zero pages, BASELINE config 5): a 16-byte unit whose bytes are all equal is ONE add of 16 instead of 16 adds of 1
+// that all go to the same address -- the lanes of a replica serialise on it (0.88 against 0.72 ms per 4 GiB on zeros + 1 %
+// noise, where 85 % of the units are runs).  The other units of the step take the 16 adds as always.
+__device__ __forceinline__ bool unit_is_run(const uint4& v) {
+    return v.x == v.y && v.x == v.z && v.x == v.w && v.x == __builtin_amdgcn_alignbit(v.x, v.x, 8);
+}
+__device__ __forceinline__ void hist_add_vec_runs(uint32_t* h, uint32_t col, const uint4& v) {
+    if (unit_is_run(v)) {
+        const uint32_t byte = v.x & 0xFFu;
+        const uint32_t idx = ((byte & 127u) << K1_CSHIFT) + col;
+        const uint32_t val = ((byte >> 7) * 0xFFFFu + 1u) << 4;  // 16 or 16 << 16
+        __hip_atomic_fetch_add(&h[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+        hist_add_vec(h, col, v);
+    }
 }
 
 // COPY: the segment is also stored, byte for byte, at the same offset of copy_out.  That is the whole encoder output when
@@ -168,10 +188,18 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_histogram(const uint8_t* __r
 #if !DCZ_K1_COPY_LATE
         store4(base, c0, c1, c2, c3);
 #endif
-        hist_add_vec(h, col, c0);
-        hist_add_vec(h, col, c1);
-        hist_add_vec(h, col, c2);
-        hist_add_vec(h, col, c3);
+        // (wave-uniform: a step whose first units are mostly runs takes the path that looks for them)
+        if (DCZ_K1_RUNS && __builtin_popcountll(__builtin_amdgcn_ballot_w64(unit_is_run(c0))) >= 32) {
+            hist_add_vec_runs(h, col, c0);
+            hist_add_vec_runs(h, col, c1);
+            hist_add_vec_runs(h, col, c2);
+            hist_add_vec_runs(h, col, c3);
+        } else {
+            hist_add_vec(h, col, c0);
+            hist_add_vec(h, col, c1);
+            hist_add_vec(h, col, c2);
+            hist_add_vec(h, col, c3);
+        }
 #if DCZ_K1_COPY_LATE
         store4(base, c0, c1, c2, c3);
 #endif

@@ -107,8 +107,12 @@ def test_histogram_kats_through_abi(pkg, vectors):
                                       (100000, 7, 99990), (3 * 32768 + 17, 5, 3 * 32768)])
 def test_histogram_windows(pkg, orc, n, off, ln):
     fs = pkg.HipFrequencyService(device=0)
+    def runs():  # runs of random bytes (both halves of the packed counters), 1..200 long: K1 adds a 16-byte unit of
+        rng = np.random.default_rng(n)  # equal bytes as one add of 16, unit by unit, next to units that are not runs
+        return np.repeat(rng.integers(0, 256, size=n, dtype=np.uint8), rng.integers(1, 200, size=n))[:n]
+
     for gen in (lambda: orc.java_random_bytes(n, n), lambda: orc.gen_lowentropy(n, 0, n),
-                lambda: np.zeros(n, np.uint8), lambda: np.full(n, 255, np.uint8)):
+                lambda: np.zeros(n, np.uint8), lambda: np.full(n, 255, np.uint8), runs):
         d = gen()
         assert (fs.compute_histogram(d, off, ln) == orc.histogram(d, off, ln)).all()
     fs.close()
