@@ -31,14 +31,15 @@ namespace dcz {
 #define DCZ_K3_WAVES 4
 #endif
 #ifndef DCZ_K3_COPIES
-#define DCZ_K3_COPIES 8
+#define DCZ_K3_COPIES 4
 #endif
 #ifndef DCZ_K3_LAZY_FLUSH
 #define DCZ_K3_LAZY_FLUSH 1  // flush the ring only when the next step might not fit (0: after every step)
 #endif
 constexpr int K3_WAVES = DCZ_K3_WAVES;    // waves (= segments) per workgroup
-constexpr int K3_COPIES = DCZ_K3_COPIES;  // codebook replicas: 32 would be conflict-free, 8 (4 lanes per replica, a few
-                                          // 2-way conflicts) leaves room for 6 workgroups per CU and measures ~10 % faster
+constexpr int K3_COPIES = DCZ_K3_COPIES;  // codebook replicas: 32 would be conflict-free; 8 (a few 2-way conflicts) leaves room
+                                          // for 6 workgroups per CU and measures ~10 % faster; 4 for 7 (what the registers
+                                          // allow): text 1.75 -> 1.68 ms per 4 GiB half, zeros + noise 1.18 -> 1.11; 16: 2.06 / 1.43
 constexpr int K3_CSHIFT = (K3_COPIES == 32) ? 5 : (K3_COPIES == 16) ? 4 : (K3_COPIES == 8) ? 3 : 2;
 constexpr int RING_WORDS = 1024;     // 4 KiB per wave = 32768 bits
 constexpr uint32_t RING_MASK = RING_WORDS - 1;
