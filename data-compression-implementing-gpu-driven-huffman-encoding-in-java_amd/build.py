@@ -33,10 +33,11 @@ def build_host(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI] + srcs + ["-L" + HERE, "-ldczhip", "-Wl,-rpath,$ORIGIN"]
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI + ".part"] + srcs + ["-L" + HERE, "-ldczhip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(CLI + ".part", CLI)
     return CLI
 
 
@@ -61,18 +62,22 @@ def build(force=False, verbose=False, extra_flags=(), so=None, objdir=None):
         obj = os.path.join(objdir, f.replace(".hip", ".o"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             return obj
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        # (written under another name and moved into place: a build that is killed half-way must not leave a file that the
+        #  time stamps call fresh -- a library left behind by an interrupted session took GPU exceptions in round 3)
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj + ".part.o"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(obj + ".part.o", obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so + ".part"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(so + ".part", so)
     if main:
         build_host(True, verbose)
     return so

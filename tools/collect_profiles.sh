@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: collect_profiles.sh <tag> <round prefix, e.g. r02>   -- copies the summaries of refresh_profiles.sh into profiles/
 V=$1; P=$2
-for w in random8g text8g lowentropy text32m; do for k in bench.json kernel_stats.csv sq.txt traffic.txt; do
+for w in random8g text8g lowentropy text32m text256 random256m; do for k in bench.json kernel_stats.csv sq.txt traffic.txt; do
   [ -f gpurun_out/prof_${V}_${w}_$k ] && cp gpurun_out/prof_${V}_${w}_$k profiles/${P}_${V}_${w}_$k; done; done
 for w in random8g random256m text text8g lowentropy text_32m 2rank; do [ -f gpurun_out/bench_${w}_$V.json ] && cp gpurun_out/bench_${w}_$V.json profiles/${P}_bench_${w}_$V.json; done
 ls profiles | grep "${P}_" | wc -l

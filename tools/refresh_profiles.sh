@@ -17,6 +17,8 @@ bash tools/profile_workload.sh ${V}_random8g
 bash tools/profile_workload.sh ${V}_text8g --workload text8g
 bash tools/profile_workload.sh ${V}_lowentropy --workload lowentropy
 bash tools/profile_workload.sh ${V}_text32m --workload text_32m
+bash tools/profile_workload.sh ${V}_text256 --workload text
+bash tools/profile_workload.sh ${V}_random256m --workload random256m
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_random8g_$V.json 2> gpurun_out/bench_random8g_$V.err || echo "bench default failed"
 
 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --no-secondary --gpus 2 --backend gloo --single-device --bytes-per-gpu 2147483648 --cpu-sample-mib 0 > gpurun_out/bench_2rank_$V.json 2> gpurun_out/bench_2rank_$V.err || echo "2rank failed"
