@@ -1637,3 +1637,40 @@ def test_identity_blocks_are_stored_in_place_by_the_histogram_pass(pkg, orc):
     assert list(st[:10]) == [0] * 10 and (st[10:] == pkg.native.DCZ_E_CAPACITY).all()
     assert (out.payload[: 10 * bb].cpu().numpy() == rnd[: 10 * bb]).all()
     assert bool((guard == 0x5A).all())
+
+
+def test_bench_line_keeps_the_drivers_contract():
+    """bench.py on a small slice of the default workload, run the way the driver runs it (its own process, one JSON line on
+    stdout): the keys the driver and the judge read are there, the arithmetic inside the line is consistent (frac =
+    achieved / peak, value = bytes / time), the round trip was verified, and no figure exceeds the HBM peak."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--bytes-per-gpu",
+           str(256 << 20), "--cpu-sample-mib", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["unit"] == "GB/s" and d["dtype"] == "u8"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["verified_bit_exact_round_trip"] is True
+    n = d["config"]["bytes_per_gpu"]
+    assert n == 256 << 20
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.0 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * rf["achieved"]
+    assert "traffic" in rf  # HBM bytes from the offline PMC pass, or null when the launch mix differs
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 2 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "GB/s"
+    for kname, kv in d["kernels"].items():
+        assert (kv.get("gbps") or 0.0) <= 8000.0, (kname, kv)
