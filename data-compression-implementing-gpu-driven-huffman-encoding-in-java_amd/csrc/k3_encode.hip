@@ -266,7 +266,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_encode(const uint8_t* __rest
                                                             const unsigned long long* __restrict__ d_seg_bitoff,
                                                             const int32_t* __restrict__ d_status,
                                                             uint8_t* __restrict__ out) {
-    // one array: [0, 8192) codebook (32 KiB), then 8 rings of 1024 dwords (32 KiB)
+    // one array: the codebook (256 entries x K3_COPIES replicas), then one ring of 1024 (+ 4) dwords per wave
     __shared__ __attribute__((aligned(16))) uint32_t lds[256 * K3_COPIES + K3_WAVES * RING_STRIDE];
     const uint32_t b = blockIdx.x / groups_per_block;
     const uint32_t grp = blockIdx.x % groups_per_block;
