@@ -71,6 +71,9 @@ namespace dcz {
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
+#ifndef DCZ_DFA_X_FROM_SPARSE
+#define DCZ_DFA_X_FROM_SPARSE 48  // first nibble of the exit-only walk of the SPARSE instantiations
+#endif
 #ifndef DCZ_DFA_SPARSE_OC
 #define DCZ_DFA_SPARSE_OC 16384  // SPARSE: bytes of output composed per chunk (a window is ~60 KiB of output): what four workgroups
 #endif                           // per CU leave after the table (16 KiB) and the lists (6.8 KiB)
@@ -549,7 +552,11 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     }(std::make_integer_sequence<int, 32>{});
                     e = st6 << 6;
                 } else if (round == 0u) {  // workgroup-uniform
-                    if (DCZ_DFA_X_FROM > 0) e = 0;  // (mid-subsequence every lane guesses "codeword boundary")
+                    // (SPARSE starts later: in a run of the 1-bit symbol every position is a codeword boundary, a wrong guess is
+                    //  put right by the first such run -- from nibble 16: 2.75 ms on config 5's slice, 40: 2.68, 48: 2.63,
+                    //  56: 2.62; 1 GiB at 3 % noise: 0.66 / 0.63 / 0.61 / 0.65 ms: tools/sparse_noise.py)
+                    constexpr int XF = SPARSE ? DCZ_DFA_X_FROM_SPARSE : DCZ_DFA_X_FROM;
+                    if (XF > 0) e = 0;  // (mid-subsequence every lane guesses "codeword boundary")
                     DFA_RJ_DECL;
                     auto stepX = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
@@ -562,8 +569,8 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     // nibbles (text synchronises within 5 nibbles on average, 0.03 % of the subsequences need more
                     // than 48); a wrong exit is found and repaired by the rounds that follow.  Text 8 GiB: 8.37 ms from nibble 0, 8.02 from 16 or 24, 8.34 from 32 (more repair rounds), 8.98 from 48.
                     [&]<int... Js>(std::integer_sequence<int, Js...>) {
-                        (stepX(std::integral_constant<int, DCZ_DFA_X_FROM + Js>{}), ...);
-                    }(std::make_integer_sequence<int, 64 - DCZ_DFA_X_FROM>{});
+                        (stepX(std::integral_constant<int, XF + Js>{}), ...);
+                    }(std::make_integer_sequence<int, 64 - XF>{});
                 } else if constexpr (SPARSE) {
                     // One walk counts and records: (index inside the subsequence, byte) of every symbol other than z goes
                     // into the lane's list.  The entry is stored every step and the list pointer moves on only when the
