@@ -71,6 +71,10 @@ namespace dcz {
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
+#ifndef DCZ_DFA_X6_BIT0
+#define DCZ_DFA_X6_BIT0 64  // first bit of the six-bit exit-only walk (256 - this must be a multiple of 6): text 8 GiB K4 from bit 40
+                            // 6.91 ms, 64: 6.89, 88: 7.01, 112: 7.39
+#endif
 #ifndef DCZ_DFA_X_FROM_SPARSE
 #define DCZ_DFA_X_FROM_SPARSE 48  // first nibble of the exit-only walk of the SPARSE instantiations
 #endif
@@ -534,14 +538,16 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
                 uint32_t e = g << 6, n = 0;
                 if (round == 0u && small) {  // workgroup-uniform: 32 steps of six bits over the last 192 bits
+                    constexpr int X6_BIT0 = DCZ_DFA_X6_BIT0, X6_STEPS = (256 - X6_BIT0) / 6;
+                    static_assert(X6_BIT0 + 6 * X6_STEPS == 256, "the six-bit walk ends on the subsequence's last bit");
                     uint32_t rq[8], st6 = 0;  // (copies the compiler cannot see through: nothing of this walk is kept in
 #pragma unroll                                //  registers across the rounds, unlike the nibble offsets)
-                    for (int k = 2; k < 8; k++) {
+                    for (int k = X6_BIT0 >> 5; k < 8; k++) {
                         rq[k] = R[k];
                         asm volatile("" : "+v"(rq[k]));
                     }
                     auto stepX6 = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int pbit = 64 + 6 * decltype(ic)::value, k = pbit >> 5, off = pbit & 31;
+                        constexpr int pbit = X6_BIT0 + 6 * decltype(ic)::value, k = pbit >> 5, off = pbit & 31;
                         uint32_t v;
                         if constexpr (off <= 26) v = (rq[k] >> (26 - off)) & 63u;
                         else v = __builtin_amdgcn_alignbit(rq[k], rq[k < 7 ? k + 1 : 7], 58 - off) & 63u;
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
                     };
                     [&]<int... Is>(std::integer_sequence<int, Is...>) {
                         (stepX6(std::integral_constant<int, Is>{}), ...);
-                    }(std::make_integer_sequence<int, 32>{});
+                    }(std::make_integer_sequence<int, X6_STEPS>{});
                     e = st6 << 6;
                 } else if (round == 0u) {  // workgroup-uniform
                     // (SPARSE starts later: in a run of the 1-bit symbol every position is a codeword boundary, a wrong guess is
