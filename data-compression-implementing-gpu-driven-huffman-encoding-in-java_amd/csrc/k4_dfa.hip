@@ -71,6 +71,12 @@ namespace dcz {
 #ifndef DCZ_DFA_X_FROM
 #define DCZ_DFA_X_FROM 16  // first nibble of the exit-only walk (0: the whole subsequence)
 #endif
+#ifndef DCZ_DFA_KATTR
+#define DCZ_DFA_KATTR  // debugging: an attribute for every k4_dfa instantiation, e.g. __attribute__((amdgpu_num_vgpr(120)))
+#endif
+#ifndef DCZ_DFA_ALLWALK
+#define DCZ_DFA_ALLWALK 0  // debugging: every wave walks in every round, whether one of its lanes needs it or not
+#endif
 #ifndef DCZ_DFA_X6_BIT0
 #define DCZ_DFA_X6_BIT0 64  // first bit of the six-bit exit-only walk (256 - this must be a multiple of 6): text 8 GiB K4 from bit 40
                             // 6.91 ms, 64: 6.89, 88: 7.01, 112: 7.39
@@ -221,7 +227,7 @@ __device__ unsigned long long dfa_prof[12];  // [8] windows, [9] rounds, [10] fl
 // (rounds of phase A only) and reports (entry state, symbols completed inside the region, exit state).
 // k4_split_scan proves the chain exit(r-1) == entry(r): equal states at the same byte are the same parse from there on.
 template <int W, int OC, int MODE, bool SPARSE>
-__global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
+__global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) DCZ_DFA_KATTR void k4_dfa(
     const uint8_t* __restrict__ comp, const unsigned long long* __restrict__ d_comp_off,
     const uint32_t* __restrict__ d_comp_size, const uint32_t* __restrict__ d_orig_size, const uint8_t* __restrict__ d_len,
     size_t out_stride, uint8_t* __restrict__ out, int32_t* __restrict__ d_status, long long* __restrict__ d_errpos,
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) void k4_dfa(
         bool need = !beyond;
         uint32_t round = (DCZ_DFA_ABL & 4) ? 1u : 0u;
         while (true) {
-            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
+            if (DCZ_DFA_ALLWALK || __builtin_amdgcn_ballot_w64(need) != 0ull) {  // wave-uniform: somebody in this wave walks
                 uint32_t e = g << 6, n = 0;
                 if (round == 0u && small) {  // workgroup-uniform: 32 steps of six bits over the last 192 bits
                     constexpr int X6_BIT0 = DCZ_DFA_X6_BIT0, X6_STEPS = (256 - X6_BIT0) / 6;
