@@ -4,13 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-__global__ __launch_bounds__(1024, 1) void vtest(const uint32_t* in, unsigned long long* bad, int iters, int reg) {
+__global__ __launch_bounds__(1024, 1) void vtest(const uint32_t* in, unsigned long long* bad, int iters, int reg, int active_waves) {
     __shared__ uint32_t T[4096 + 34 * 1024];
     const int tid = threadIdx.x;
     for (int i = tid; i < 4096; i += 1024) T[i] = in[i];
     __syncthreads();
     uint32_t e = in[tid & 4095], acc = 0, slot = 4096 + 34 * tid;
     unsigned long long nbad = 0;
+    if ((tid >> 6) >= active_waves) iters = 0;  // the other waves leave: an LDS read then returns within a few cycles
     for (int it = 0; it < iters; it++) {
         const uint32_t e0 = T[(e >> 6) & 4095];
         const uint32_t e1 = T[(e0 >> 6) & 4095];
@@ -26,7 +27,6 @@ __global__ __launch_bounds__(1024, 1) void vtest(const uint32_t* in, unsigned lo
         acc |= w;
         T[slot + (it & 31)] = acc;
         e = e1 + it;
-        if ((it & 63) == 63) __syncthreads();
     }
     if (nbad) atomicAdd(bad, nbad);
     if (acc == 0x12345678u) bad[1] = 1;
@@ -37,12 +37,14 @@ int main() {
     for (int i = 0; i < 4096; i++) { s = s * 1664525u + 1013904223u; h[i] = s; }
     uint32_t* d; unsigned long long* b;
     hipMalloc(&d, 4096 * 4); hipMalloc(&b, 16); hipMemcpy(d, h, 4096 * 4, hipMemcpyHostToDevice);
-    for (int reg : {127, 119}) {
-        hipMemset(b, 0, 16);
-        hipLaunchKernelGGL(vtest, dim3(256), dim3(1024), 0, 0, d, b, 200000, reg);
-        unsigned long long r[2];
-        hipMemcpy(r, b, 16, hipMemcpyDeviceToHost);
-        printf("count held in v%d: %llu mismatches in %llu steps (%s)\n", reg, r[0], 256ull * 1024 * 200000, hipGetErrorString(hipGetLastError()));
-    }
+    for (int aw : {16, 4, 2, 1})
+        for (int reg : {127, 119}) {
+            hipMemset(b, 0, 16);
+            hipLaunchKernelGGL(vtest, dim3(256), dim3(1024), 0, 0, d, b, 400000, reg, aw);
+            unsigned long long r[2];
+            hipMemcpy(r, b, 16, hipMemcpyDeviceToHost);
+            printf("%2d waves of 16 active, count held in v%d: %llu mismatches in %llu steps (%s)\n", aw, reg, r[0], 256ull * 64 * aw * 400000,
+                   hipGetErrorString(hipGetLastError()));
+        }
     return 0;
 }
