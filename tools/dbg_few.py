@@ -21,6 +21,13 @@ for rep in range(3):
     dec = out[:n].cpu().numpy()
     bad = np.nonzero(dec != data)[0]
     print("rep", rep, "status", np.unique(st.cpu().numpy()).tolist(), "mismatches", bad.size, "in blocks", np.unique(bad // bb).tolist()[:10])
+import ctypes
+if hasattr(pkg.lib(), "dcz_debug_dfa_dbg"):  # -DDCZ_DFA_DBG=1: what the walk stamped into its slot against what the compaction read
+    f = pkg.lib().dcz_debug_dfa_dbg
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 8)()
+    f(buf, 1)
+    print("dbg: lanes compared %d, count differs %d, checksum(walk) != checksum(slot at compaction) %d" % (buf[0], buf[1], buf[3]))
 if bad.size:
     lens = blk.code_lengths.cpu().numpy().astype(np.int64)
     shown = 0
