@@ -63,7 +63,8 @@ namespace dcz {
 #define DCZ_DFA_HOIST_DW_SPLIT 3
 #endif
 #ifndef DCZ_DFA_HOIST_DW_REC
-#define DCZ_DFA_HOIST_DW_REC 7  // (8 spills three registers at four waves per SIMD)
+#define DCZ_DFA_HOIST_DW_REC 0  // (8 spills three registers at four waves per SIMD; 7: 127 registers, text 8 GiB 6.81 ms; 5: 6.62;
+                                 //  4, 2, 0: 6.48 with 104-116 registers -- the kernel waits for LDS, it is not short of issue slots)
 #endif
 #ifndef DCZ_DFA_HOIST_DW_1024
 #define DCZ_DFA_HOIST_DW_1024 5
