@@ -66,6 +66,10 @@ namespace dcz {
 #define DCZ_DFA_HOIST_DW_REC 0  // (8 spills three registers at four waves per SIMD; 7: 127 registers, text 8 GiB 6.81 ms; 5: 6.62;
                                  //  4, 2, 0: 6.48 with 104-116 registers -- the kernel waits for LDS, it is not short of issue slots)
 #endif
+#ifndef DCZ_DFA_HOIST_DW_COUNT
+#define DCZ_DFA_HOIST_DW_COUNT 8  // the counting pass of the split decoder (no recording: its registers are free; 0 or 4: 32 MiB
+                                  // chunks K4 1.60 -> 1.58 ms, within the noise)
+#endif
 #ifndef DCZ_DFA_HOIST_DW_1024
 #define DCZ_DFA_HOIST_DW_1024 5
 #endif
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(W, W > 512 ? 1 : DCZ_DFA_MINWAVES) DCZ_DFA_KATTR vo
     constexpr bool SPLIT = MODE == 1, COUNT = MODE == 2;
     constexpr bool RECORD = OC < 0;  // the walk that counts also records the symbols (DfaLds: the slot area is the tile)
     static_assert(!RECORD || (!SPARSE && !COUNT), "only the decoding passes of the dense automaton record");
-    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : COUNT ? 8 : DCZ_DFA_HOIST_DW_REC;
+    constexpr int HOIST_DW = !DCZ_DFA_HOIST ? 0 : SPLIT ? DCZ_DFA_HOIST_DW_SPLIT : W > 512 ? DCZ_DFA_HOIST_DW_1024 : COUNT ? DCZ_DFA_HOIST_DW_COUNT : DCZ_DFA_HOIST_DW_REC;
     __shared__ LdsT L;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
